@@ -1,0 +1,114 @@
+"""Synthetic T3 checkpoints with the reference's safetensors key names/shapes.
+
+No real weights exist offline, so tests and bench.py build
+checkpoints from a fixed numpy PCG64 seed: linear weights
+N(0, .02^2), RMSNorm weights 1 + N(0, .1^2), embeddings / head N(0, .02^2).
+Key names follow R/t3.R:1065-1097 and R/llama.R:566-607 of the reference so
+the native loader is exercised on the layout of the real `t3_cfg.safetensors`.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Dict
+
+import numpy as np
+
+F32 = np.float32
+
+
+@dataclass(frozen=True)
+class T3Dims:
+    """Shapes of the Llama-backbone T3 (R/llama.R:20-45, R/t3.R:11-36)."""
+    hidden_size: int = 1024
+    intermediate_size: int = 4096
+    num_hidden_layers: int = 30
+    num_attention_heads: int = 16
+    head_dim: int = 64
+    speech_vocab: int = 8194
+    max_speech_pos: int = 4100
+    start_speech_token: int = 6561
+    stop_speech_token: int = 6562
+
+
+FULL = T3Dims()
+# reduced shape for committed goldens / fast CPU parity (head_dim stays 64)
+TINY = T3Dims(hidden_size=256, intermediate_size=1024, num_hidden_layers=2,
+              num_attention_heads=4, head_dim=64, speech_vocab=1000, max_speech_pos=600,
+              start_speech_token=990, stop_speech_token=991)
+
+
+def synth_llama_weights(dims: T3Dims, seed: int = 1234) -> Dict[str, np.ndarray]:
+    rng = np.random.Generator(np.random.PCG64(seed))
+    d, F, V = dims.hidden_size, dims.intermediate_size, dims.speech_vocab
+
+    def lin(o, i):
+        return (rng.standard_normal((o, i), dtype=F32) * F32(0.02)).astype(F32)
+
+    def nrm():
+        return (F32(1.0) + rng.standard_normal(d, dtype=F32) * F32(0.1)).astype(F32)
+
+    w: Dict[str, np.ndarray] = {}
+    for i in range(dims.num_hidden_layers):
+        p = f"tfmr.layers.{i}."
+        w[p + "input_layernorm.weight"] = nrm()
+        w[p + "self_attn.q_proj.weight"] = lin(d, d)
+        w[p + "self_attn.k_proj.weight"] = lin(d, d)
+        w[p + "self_attn.v_proj.weight"] = lin(d, d)
+        w[p + "self_attn.o_proj.weight"] = lin(d, d)
+        w[p + "post_attention_layernorm.weight"] = nrm()
+        w[p + "mlp.gate_proj.weight"] = lin(F, d)
+        w[p + "mlp.up_proj.weight"] = lin(F, d)
+        w[p + "mlp.down_proj.weight"] = lin(d, F)
+    w["tfmr.norm.weight"] = nrm()
+    w["speech_emb.weight"] = lin(V, d)
+    w["speech_pos_emb.emb.weight"] = lin(dims.max_speech_pos, d)
+    w["speech_head.weight"] = lin(V, d)
+    return w
+
+
+def synth_embeds(rows: int, s0: int, d: int, seed: int) -> np.ndarray:
+    """Prompt embeddings ~ N(0, .53^2) (the std of the real activations in the
+    reference's outputs/cond_enc_debug.safetensors), shape [rows, s0, d]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return (rng.standard_normal((rows, s0, d), dtype=F32) * F32(0.53)).astype(F32)
+
+
+def write_safetensors(weights: Dict[str, np.ndarray], path: str) -> str:
+    """Plain safetensors writer (8-byte LE header length, JSON header, raw data)
+    so no third-party package is needed on the GPU box."""
+    import json
+    header = {}
+    off = 0
+    names = sorted(weights.keys())
+    for k in names:
+        a = weights[k]
+        assert a.dtype == np.float32
+        n = a.size * 4
+        header[k] = {"dtype": "F32", "shape": list(a.shape), "data_offsets": [off, off + n]}
+        off += n
+    hj = json.dumps(header, separators=(",", ":")).encode()
+    hj += b" " * ((8 - len(hj) % 8) % 8)
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        f.write(len(hj).to_bytes(8, "little"))
+        f.write(hj)
+        for k in names:
+            f.write(np.ascontiguousarray(weights[k]).tobytes())
+    os.replace(tmp, path)
+    return path
+
+
+def checkpoint_path(dims: T3Dims, seed: int = 1234, root: str | None = None) -> str:
+    root = root or os.environ.get("T3MI_SYNTH_DIR", "/tmp/t3mi_synth")
+    os.makedirs(root, exist_ok=True)
+    tag = f"t3_L{dims.num_hidden_layers}_d{dims.hidden_size}_F{dims.intermediate_size}_V{dims.speech_vocab}_s{seed}"
+    return os.path.join(root, tag + ".safetensors")
+
+
+def ensure_checkpoint(dims: T3Dims, seed: int = 1234, root: str | None = None) -> str:
+    """Create the synthetic checkpoint file once and return its path."""
+    path = checkpoint_path(dims, seed, root)
+    if not os.path.exists(path):
+        write_safetensors(synth_llama_weights(dims, seed), path)
+    return path
