@@ -1,0 +1,9 @@
+"""chatterbox_amd -- MI355X-native T3 speech-token decoder behind chatterbox's
+`t3_inference()` interface (hand-written gfx950 HIP kernels + a C-ABI library).
+
+Only the T3 decode hot path lives here; the rest of the reference
+(tokenizers, voice encoders, S3Gen, vocoder, download) is out of scope."""
+from .t3 import (Session, T3Model, load_t3, t3_inference, t3_inference_batch,  # noqa: F401
+                 t3_inference_cpp)
+
+__version__ = "0.1.0"

@@ -1,0 +1,695 @@
+// gfx950 (MI355X, CDNA4) kernels of the T3 decode hot path.  wave = 64 lanes.
+//
+// Decode at 1-4 activation rows is a pure weight stream (2.05 GB fp32 per step):
+// every kernel here is HBM-bound and is shaped for memory-level parallelism, not FLOPs --
+// weights go straight from HBM to VGPRs as 16-byte loads, one 1-KiB contiguous piece per
+// wave-instruction, all of a wave's loads issued before the first use; no LDS staging for
+// operands that are read once (cdna guide, "GEMV / M <= 16" row).  The activation rows share
+// one pass over the weights (the CFG cond/uncond pair costs one weight read, not two).
+//
+// Summation orders are fixed (no atomics), so results are bit-reproducible run to run.
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace t3k {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kHeadDim = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
+// ---- weight element types --------------------------------------------------------------
+struct F32W {
+    static constexpr int E = 4;  // elements per 16-byte load
+    __device__ static __forceinline__ void load(const void* base, size_t elem_off, float (&o)[4]) {
+        const float4 v = *reinterpret_cast<const float4*>(static_cast<const float*>(base) + elem_off);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+};
+struct BF16W {
+    static constexpr int E = 8;
+    __device__ static __forceinline__ void load(const void* base, size_t elem_off, float (&o)[8]) {
+        const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(base) + elem_off);
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xFFFF0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xFFFF0000u);
+        o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xFFFF0000u);
+        o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xFFFF0000u);
+    }
+};
+
+// ---- GEMV: y[r][n] = sum_k W[n][k] * xn[r][k], 4 output rows per wave-chunk ------------------
+//
+// A wave owns a "chunk" of 4 output features and the whole K (KSPLIT==1) or one quarter of K
+// (KSPLIT==4, the 4 waves of the block then combine through LDS in a fixed order).  Lane l holds
+// k = c*64*E + l*E .. +E-1 of every row, so one wave-instruction reads 1 KiB contiguous.
+// Which 4 features form a chunk depends on the epilogue:
+//   STORE/RESID : n = 4c .. 4c+3
+//   ROPE_KV     : matrix hm = c/16 (q heads, k heads, v heads), i0 = 2*(c%16):
+//                 n = hm*64 + {i0, i0+1, i0+32, i0+33}   -> both halves of a rotate_half pair
+//   SWIGLU      : gate rows {2c, 2c+1} and up rows {F+2c, F+2c+1} (F = N/2)
+template <int EPI>
+__device__ __forceinline__ int chunk_row(int c, int j, int N) {
+    if (EPI == EPI_ROPE_KV) {
+        const int hm = c >> 4, i0 = (c & 15) << 1;
+        return hm * kHeadDim + i0 + (j & 1) + ((j >> 1) << 5);
+    } else if (EPI == EPI_SWIGLU) {
+        return (j >> 1) * (N >> 1) + 2 * c + (j & 1);
+    } else {
+        return 4 * c + j;
+    }
+}
+
+template <typename WT, int R, int NK, int KSPLIT, int EPI, bool NORM>
+__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a, int n_chunks) {
+    constexpr int E = WT::E;
+    constexpr int KW = NK * kWave * E;  // K elements handled by one wave
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int K = KW * KSPLIT;
+    const int kbase = (KSPLIT > 1) ? wave * KW : 0;
+
+    int c = (KSPLIT > 1) ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const int cstride = (KSPLIT > 1) ? (int)gridDim.x : (int)gridDim.x * 4;
+
+    // ---- issue the first chunk's weight loads before touching x (longest latency first)
+    float w[4][NK][E];
+    auto load_chunk = [&](int cc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int row = chunk_row<EPI>(cc, j, a.N);
+            row = row < a.N ? row : a.N - 1;
+            const size_t off = (size_t)row * K + kbase + lane * E;
+#pragma unroll
+            for (int q = 0; q < NK; ++q) WT::load(a.W, off + (size_t)q * kWave * E, w[j][q]);
+        }
+    };
+    if (c < n_chunks) load_chunk(c);
+
+    // ---- activation rows for this lane's k-slice (+ fused RMSNorm, R/llama.R:65-72)
+    float xv[R][NK][E];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < NK; ++q)
+#pragma unroll
+            for (int e4 = 0; e4 < E; e4 += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(a.x + (size_t)r * K + kbase + q * kWave * E + lane * E + e4);
+                xv[r][q][e4 + 0] = v.x; xv[r][q][e4 + 1] = v.y; xv[r][q][e4 + 2] = v.z; xv[r][q][e4 + 3] = v.w;
+            }
+    if (NORM) {
+        static_assert(!NORM || KSPLIT == 1, "norm prologue needs the whole row in one wave");
+        float lw[NK][E];
+#pragma unroll
+        for (int q = 0; q < NK; ++q)
+#pragma unroll
+            for (int e4 = 0; e4 < E; e4 += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(a.ln_w + q * kWave * E + lane * E + e4);
+                lw[q][e4 + 0] = v.x; lw[q][e4 + 1] = v.y; lw[q][e4 + 2] = v.z; lw[q][e4 + 3] = v.w;
+            }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float ss = 0.f;
+#pragma unroll
+            for (int q = 0; q < NK; ++q)
+#pragma unroll
+                for (int e = 0; e < E; ++e) ss = fmaf(xv[r][q][e], xv[r][q][e], ss);
+            ss = wave_sum(ss);
+            const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+#pragma unroll
+            for (int q = 0; q < NK; ++q)
+#pragma unroll
+                for (int e = 0; e < E; ++e) xv[r][q][e] = __fmul_rn(lw[q][e], __fmul_rn(xv[r][q][e], rs));
+        }
+    }
+
+    __shared__ float part[4][4][R];
+
+    for (; c < n_chunks; c += cstride) {
+        float acc[4][R];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < NK; ++q)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) s = fmaf(w[j][q][e], xv[r][q][e], s);
+                acc[j][r] = s;
+            }
+        const int cn = c + cstride;
+        if (cn < n_chunks) load_chunk(cn);  // next chunk's loads fly during the reduction
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[j][r] = wave_sum(acc[j][r]);
+
+        if (KSPLIT > 1) {
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) part[wave][j][r] = acc[j][r];
+            }
+            __syncthreads();
+            if (threadIdx.x < 4 * R) {
+                const int j = threadIdx.x / R, r = threadIdx.x % R;
+                float s = part[0][j][r];
+#pragma unroll
+                for (int ww = 1; ww < KSPLIT; ++ww) s += part[ww][j][r];
+                const int n = chunk_row<EPI>(c, j, a.N);
+                if (n < a.N) {
+                    const size_t o = (size_t)r * a.ldy + n;
+                    a.y[o] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o], s) : s;
+                }
+            }
+            __syncthreads();
+        } else if (EPI == EPI_STORE || EPI == EPI_RESID) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (lane == j * R + r) {
+                        const int n = 4 * c + j;
+                        if (n < a.N) {
+                            const size_t o = (size_t)r * a.ldy + n;
+                            a.y[o] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o], acc[j][r]) : acc[j][r];
+                        }
+                    }
+        } else if (EPI == EPI_SWIGLU) {
+            // silu(g) * u with silu(g) = g * sigmoid(g)  (R/llama.R:302, 307)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (lane == j * R + r) {
+                        const float g = acc[j][r], u = acc[j + 2][r];
+                        const float sg = 1.0f / (1.0f + expf(-g));
+                        a.y[(size_t)r * a.ldy + 2 * c + j] = __fmul_rn(__fmul_rn(g, sg), u);
+                    }
+        } else {  // EPI_ROPE_KV
+            const int H = a.n_heads;
+            const int hm = c >> 4, i0 = (c & 15) << 1;
+            const int kind = hm / H, head = hm % H;  // 0 q, 1 k, 2 v
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (lane == jj * R + r) {
+                        const int pos = a.rowpos[r];
+                        if (pos >= 0) {
+                            const int i = i0 + jj;
+                            float lo = acc[jj][r], hi = acc[jj + 2][r];
+                            if (kind < 2) {
+                                // q*cos + rotate_half(q)*sin, each product rounded (R/llama.R:184-185)
+                                const float cl = a.rope_cos[(size_t)pos * kHeadDim + i];
+                                const float sl = a.rope_sin[(size_t)pos * kHeadDim + i];
+                                const float ch = a.rope_cos[(size_t)pos * kHeadDim + i + 32];
+                                const float sh = a.rope_sin[(size_t)pos * kHeadDim + i + 32];
+                                const float nlo = __fadd_rn(__fmul_rn(lo, cl), __fmul_rn(-hi, sl));
+                                const float nhi = __fadd_rn(__fmul_rn(hi, ch), __fmul_rn(lo, sh));
+                                lo = nlo; hi = nhi;
+                            }
+                            if (kind == 0) {
+                                float* q = a.y + (size_t)r * a.ldy + head * kHeadDim;
+                                q[i] = lo; q[i + 32] = hi;
+                            } else {
+                                float* cbase = (kind == 1 ? a.kcache : a.vcache) +
+                                               (((size_t)r * H + head) * a.max_len + pos) * kHeadDim;
+                                cbase[i] = lo; cbase[i + 32] = hi;
+                            }
+                        }
+                    }
+        }
+    }
+}
+
+// ---- single-query attention over the KV cache (R/llama.R:257-264, src/t3_decode.cpp:151-160) --
+// grid (H, rows); block 256 = 16 groups of 16 lanes; a group owns one key at a time, each lane 4 dims.
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+    extern __shared__ float smem[];
+    const int h = blockIdx.x, r = blockIdx.y;
+    const int pos = a.rowpos[r];
+    if (pos < 0) return;
+    const int L = pos + 1;
+    const int tid = threadIdx.x, g = tid >> 4, sub = tid & 15;
+    const int d = a.n_heads * kHeadDim;
+    float* sc = smem;                 // [max_len]
+    float* red = smem + a.max_len;    // [16][64] + 8
+    const size_t base = ((size_t)r * a.n_heads + h) * a.max_len * kHeadDim;
+    const float* Kp = a.kcache + base;
+    const float* Vp = a.vcache + base;
+    const float4 q4 = *reinterpret_cast<const float4*>(a.q + (size_t)r * d + h * kHeadDim + sub * 4);
+
+    for (int j0 = g; j0 < L; j0 += 64) {
+        float dot[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 16 * u;
+            const int jc = j < L ? j : L - 1;
+            const float4 k4 = *reinterpret_cast<const float4*>(Kp + (size_t)jc * kHeadDim + sub * 4);
+            dot[u] = fmaf(q4.w, k4.w, fmaf(q4.z, k4.z, fmaf(q4.y, k4.y, q4.x * k4.x)));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) dot[u] += __shfl_xor(dot[u], o, 16);
+            const int j = j0 + 16 * u;
+            if (sub == 0 && j < L) sc[j] = dot[u] * 0.125f;  // 1/sqrt(64)
+        }
+    }
+    __syncthreads();
+    // softmax over sc[0..L)
+    float m = -INFINITY;
+    for (int j = tid; j < L; j += 256) m = fmaxf(m, sc[j]);
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int j = tid; j < L; j += 256) {
+        const float e = expf(sc[j] - m);
+        sc[j] = e;
+        s += e;
+    }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    // out = (e / s) @ V
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = g; j < L; j += 16) {
+        const float p = sc[j] / s;
+        const float4 v4 = *reinterpret_cast<const float4*>(Vp + (size_t)j * kHeadDim + sub * 4);
+        acc.x = fmaf(p, v4.x, acc.x); acc.y = fmaf(p, v4.y, acc.y);
+        acc.z = fmaf(p, v4.z, acc.z); acc.w = fmaf(p, v4.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(red + g * kHeadDim + sub * 4) = acc;
+    __syncthreads();
+    if (tid < kHeadDim) {
+        float o = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) o += red[gg * kHeadDim + tid];
+        a.out[(size_t)r * d + h * kHeadDim + tid] = o;
+    }
+}
+
+// ---- token-by-token prefill input: x[r] = embeds[r][t - start[r]] ---------------------------
+__global__ __launch_bounds__(256) void prefill_embed_kernel(EmbedArgs a) {
+    const int r = blockIdx.x;
+    const int p = a.t - a.start[r];
+    if (threadIdx.x == 0) a.rowpos[r] = p >= 0 ? p : -1;
+    if (p < 0) return;
+    const float* src = a.emb_rows[r] + (size_t)p * a.d;
+    for (int i = threadIdx.x; i < a.d; i += blockDim.x) a.x[(size_t)r * a.d + i] = src[i];
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t u = __float_as_uint(src[i]);
+        uint32_t rb;
+        if ((u & 0x7FFFFFFFu) > 0x7F800000u) rb = (u >> 16) | 0x40u;  // keep NaN a NaN
+        else rb = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+        dst[i] = (uint16_t)rb;
+    }
+}
+
+// ---- sampling tail: one workgroup (16 waves) per utterance ------------------------------------
+// CFG combine -> repetition penalty -> /T -> softmax -> min-p (prob space) -> renorm -> sort desc
+// -> cumsum -> top-p mask -> renorm -> draw -> EOS flag -> next-token embedding.
+// R/t3.R:518-587 ; src/t3_decode.cpp:307-388.
+constexpr int kSampThreads = 1024;
+
+__device__ __forceinline__ float block_reduce_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < kSampThreads / 64; ++i) t += scratch[i];
+    return t;
+}
+__device__ __forceinline__ float block_reduce_max(float v, float* scratch) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = scratch[0];
+#pragma unroll
+    for (int i = 1; i < kSampThreads / 64; ++i) t = fmaxf(t, scratch[i]);
+    return t;
+}
+
+__device__ __forceinline__ float counter_uniform(unsigned long long seed, unsigned long long utt,
+                                                 unsigned long long step) {
+    // splitmix64 finaliser over (seed, utterance, step); identical to oracle/t3_oracle.py
+    unsigned long long z = seed * 0x9E3779B97F4A7C15ULL + utt * 0xBF58476D1CE4E5B9ULL +
+                           step * 0x94D049BB133111EBULL + 0x2545F4914F6CDD1DULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+__global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, int npad_max) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    const int u = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int V = a.V;
+    if (a.done[u]) {
+        if (tid < a.rpu) a.rowpos[u * a.rpu + tid] = -1;
+        return;
+    }
+    // LDS carve: lg[Vpad] float | kp[npad_max] u32 | tot[1024] double | ki[npad_max] u16 | scratch[32] float | misc int[8]
+    const int Vpad = (V + 3) & ~3;
+    float* lg = reinterpret_cast<float*>(smraw);
+    uint32_t* kp = reinterpret_cast<uint32_t*>(lg + Vpad);
+    double* tot = reinterpret_cast<double*>(kp + npad_max);
+    uint16_t* ki = reinterpret_cast<uint16_t*>(tot + kSampThreads);
+    float* scratch = reinterpret_cast<float*>(ki + npad_max);
+    int* misc = reinterpret_cast<int*>(scratch + 32);
+
+    const int step = a.n_tokens[u];
+    const float* lc = a.logits + (size_t)u * a.rpu * V;
+    const uint8_t* seen = a.seen + (size_t)u * V;
+    const bool use_cfg = a.cfg_w > 0.f && a.rpu > 1;
+
+    // 1. CFG, penalty, temperature  (R/t3.R:518-537)
+    float lmax = -INFINITY;
+    for (int v = tid; v < V; v += kSampThreads) {
+        float l = lc[v];
+        if (use_cfg) l = __fadd_rn(l, __fmul_rn(a.cfg_w, __fsub_rn(l, lc[V + v])));
+        if (a.mask_stop && v == a.stop_token) l = -INFINITY;
+        if (a.penalty != 1.0f && seen[v]) {
+            if (a.variant == 2) l = (l > 0.f) ? __fdiv_rn(l, a.penalty) : __fmul_rn(l, a.penalty);  // R/t3.R:1699-1708
+            else l = __fdiv_rn(l, a.penalty);                                                       // R/t3.R:531 (Q2)
+        }
+        if (a.temperature != 1.0f) l = __fdiv_rn(l, a.temperature);
+        lg[v] = l;
+        lmax = fmaxf(lmax, l);
+    }
+    lmax = block_reduce_max(lmax, scratch);
+    // 2. softmax (R/t3.R:540)
+    float se = 0.f;
+    for (int v = tid; v < V; v += kSampThreads) {
+        const float e = expf(lg[v] - lmax);
+        lg[v] = e;
+        se += e;
+    }
+    se = block_reduce_sum(se, scratch);
+    float pmax = 0.f;
+    for (int v = tid; v < V; v += kSampThreads) {
+        const float p = __fdiv_rn(lg[v], se);
+        lg[v] = p;
+        pmax = fmaxf(pmax, p);
+    }
+    pmax = block_reduce_max(pmax, scratch);
+    // 3. min-p in probability space + renorm (R/t3.R:543-548, Q5)
+    const float thr = __fmul_rn(a.min_p, pmax);
+    float s2 = 0.f;
+    for (int v = tid; v < V; v += kSampThreads) {
+        float p = lg[v];
+        if (p < thr) p = 0.f;
+        lg[v] = p;
+        s2 += p;
+    }
+    s2 = block_reduce_sum(s2, scratch);
+    // 4. compact the non-zero entries into (prob bits, id) keys
+    if (tid == 0) misc[0] = 0;
+    __syncthreads();
+    for (int v = tid; v < V; v += kSampThreads) {
+        const float p = __fdiv_rn(lg[v], s2);
+        if (p > 0.f) {
+            const int slot = atomicAdd(&misc[0], 1);
+            kp[slot] = __float_as_uint(p);
+            ki[slot] = (uint16_t)v;
+        }
+    }
+    __syncthreads();
+    const int n = misc[0];
+    const int npad = next_pow2(n < 2 ? 2 : n);
+    for (int i = n + tid; i < npad; i += kSampThreads) {
+        kp[i] = 0u;
+        ki[i] = 0xFFFFu;
+    }
+    __syncthreads();
+    // 5. bitonic sort: descending probability, ties by ascending id (= stable descending sort)
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npad; i += kSampThreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t pa = kp[i], pb = kp[ixj];
+                    const uint16_t ia = ki[i], ib = ki[ixj];
+                    const bool a_first = (pa > pb) || (pa == pb && ia < ib);
+                    const bool up = ((i & k) == 0);
+                    if (up ? !a_first : a_first) {
+                        kp[i] = pb; kp[ixj] = pa;
+                        ki[i] = ib; ki[ixj] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // 6. inclusive cumsum in double, rounded to float per prefix (libtorch CPU cumsum semantics)
+    const int CH = (npad + kSampThreads - 1) / kSampThreads;
+    const int i0 = tid * CH;
+    double csum = 0.0;
+    for (int i = i0; i < i0 + CH && i < n; ++i) csum += (double)__uint_as_float(kp[i]);
+    tot[tid] = csum;
+    __syncthreads();
+    if (tid < 64) {
+        // wave 0: exclusive scan of the 1024 chunk totals, 16 per lane
+        double loc[16];
+        double run = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            loc[q] = run;
+            run += tot[tid * 16 + q];
+        }
+        double incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double t = __shfl_up(incl, o, kWave);
+            if (tid >= o) incl += t;
+        }
+        const double excl = incl - run;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot[tid * 16 + q] = excl + loc[q];
+    }
+    __syncthreads();
+    // cum[] aliases lg[] (the dense probabilities are no longer needed)
+    float* cum = lg;
+    {
+        double run = tot[tid];
+        for (int i = i0; i < i0 + CH && i < n; ++i) {
+            run += (double)__uint_as_float(kp[i]);
+            cum[i] = (float)run;
+        }
+    }
+    __syncthreads();
+    // 7. top-p mask: the kept set is a prefix of the sorted order
+    //    r  : keep i == 0 or cum[i]   <= top_p   (R/t3.R:557-560, drops the crossing token)
+    //    cpp: keep i == 0 or cum[i-1] <= top_p   (src/t3_decode.cpp:350-356, keeps it)
+    if (tid == 0) misc[1] = 0;
+    __syncthreads();
+    {
+        int cnt = 0;
+        for (int i = tid; i < n; i += kSampThreads) {
+            bool keep;
+            if (i == 0) keep = true;
+            else if (a.variant == 1) keep = !(cum[i - 1] > a.top_p);
+            else keep = !(cum[i] > a.top_p);
+            cnt += keep ? 1 : 0;
+        }
+        if (cnt) atomicAdd(&misc[1], cnt);
+    }
+    __syncthreads();
+    const int kkeep = misc[1];
+    float s3 = 0.f;
+    for (int i = tid; i < kkeep; i += kSampThreads) s3 += __uint_as_float(kp[i]);
+    s3 = block_reduce_sum(s3, scratch);
+    // 8. draw: inverse CDF over the kept prefix with the build's counter RNG
+    const float uu = counter_uniform(a.seed, (unsigned long long)u, (unsigned long long)step);
+    const float target = __fmul_rn(uu, cum[kkeep - 1]);
+    if (tid == 0) misc[2] = 0;
+    __syncthreads();
+    {
+        int cnt = 0;
+        for (int i = tid; i < kkeep; i += kSampThreads) cnt += (cum[i] <= target) ? 1 : 0;
+        if (cnt) atomicAdd(&misc[2], cnt);
+    }
+    __syncthreads();
+    int jsel = misc[2];
+    if (jsel > kkeep - 1) jsel = kkeep - 1;
+    int tok = (int)ki[jsel];
+    if (a.forced != nullptr && step < a.n_forced) tok = a.forced[(size_t)u * a.n_forced + step];
+
+    if (a.dist_ids != nullptr) {
+        const int m = kkeep < a.dist_cap ? kkeep : a.dist_cap;
+        for (int i = tid; i < m; i += kSampThreads) {
+            a.dist_ids[(size_t)u * a.dist_cap + i] = (int)ki[i];
+            a.dist_probs[(size_t)u * a.dist_cap + i] = __fdiv_rn(__uint_as_float(kp[i]), s3);
+        }
+        if (tid == 0) a.dist_n[u] = kkeep;
+    }
+    // 9. bookkeeping + next-token embedding (R/t3.R:569-587; src/t3_decode.cpp:365-388)
+    const int pos_next = a.s0[u] + step;  // cache slot of the token just sampled
+    int dn = 0;
+    if (tok == a.stop_token) dn = 1;
+    else if (step + 1 >= a.max_new_tokens) dn = 2;
+    else if (pos_next >= a.max_len || step + 1 >= a.max_pos) dn = 3;
+    if (tid == 0) {
+        if (step < a.cap) a.tokens[(size_t)u * a.cap + step] = tok;
+        a.n_tokens[u] = step + 1;
+        a.seen[(size_t)u * V + tok] = 1;
+        a.done[u] = dn;
+    }
+    if (tid < a.rpu) a.rowpos[u * a.rpu + tid] = dn ? -1 : pos_next;
+    if (!dn) {
+        const float* e = a.emb + (size_t)tok * a.d;
+        const float* pe = a.pos_emb + (size_t)(step + 1) * a.d;  // Q11: BOS holds row 0
+        for (int i = tid; i < a.d; i += kSampThreads) {
+            const float v = __fadd_rn(e[i], pe[i]);
+            for (int rr = 0; rr < a.rpu; ++rr) a.x[((size_t)u * a.rpu + rr) * a.d + i] = v;
+        }
+    }
+}
+
+template <typename WT, int R, int NK, int KSPLIT, int EPI, bool NORM>
+hipError_t launch_gemv_t(const GemvArgs& a, hipStream_t s) {
+    int n_chunks;
+    if (EPI == EPI_ROPE_KV) n_chunks = (a.N / kHeadDim) * 16;
+    else if (EPI == EPI_SWIGLU) n_chunks = a.N / 4;
+    else n_chunks = (a.N + 3) / 4;
+    int grid = (KSPLIT > 1) ? n_chunks : (n_chunks + 3) / 4;
+    const int max_grid = 256 * 8;
+    if (grid > max_grid) grid = max_grid;
+    hipLaunchKernelGGL((gemv_kernel<WT, R, NK, KSPLIT, EPI, NORM>), dim3(grid), dim3(256), 0, s, a, n_chunks);
+    return hipGetLastError();
+}
+
+template <typename WT, int R, int NK>
+hipError_t launch_gemv_rn(const GemvArgs& a, int epi, int ksplit, hipStream_t s) {
+    if (ksplit == 1) {
+        switch (epi) {
+            case EPI_STORE: return launch_gemv_t<WT, R, NK, 1, EPI_STORE, true>(a, s);
+            case EPI_ROPE_KV: return launch_gemv_t<WT, R, NK, 1, EPI_ROPE_KV, true>(a, s);
+            case EPI_SWIGLU: return launch_gemv_t<WT, R, NK, 1, EPI_SWIGLU, true>(a, s);
+            case EPI_RESID: return launch_gemv_t<WT, R, NK, 1, EPI_RESID, false>(a, s);
+        }
+    } else if (ksplit == 4 && epi == EPI_RESID) {
+        return launch_gemv_t<WT, R, NK, 4, EPI_RESID, false>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <typename WT>
+hipError_t launch_gemv_w(const GemvArgs& a, int epi, hipStream_t s) {
+    const int unit = kWave * WT::E;
+    if (a.K % unit) return hipErrorInvalidValue;
+    int units = a.K / unit, ksplit = 1;
+    if (units > 4) {
+        if (units % 4) return hipErrorInvalidValue;
+        units /= 4;
+        ksplit = 4;
+    }
+    if (units != 1 && units != 2 && units != 4) return hipErrorInvalidValue;
+#define T3K_DISPATCH_R(NKV)                                                      \
+    switch (a.rows) {                                                            \
+        case 1: return launch_gemv_rn<WT, 1, NKV>(a, epi, ksplit, s);            \
+        case 2: return launch_gemv_rn<WT, 2, NKV>(a, epi, ksplit, s);            \
+        case 4: return launch_gemv_rn<WT, 4, NKV>(a, epi, ksplit, s);            \
+        default: return hipErrorInvalidValue;                                    \
+    }
+    if (units == 1) { T3K_DISPATCH_R(1) }
+    if (units == 2) { T3K_DISPATCH_R(2) }
+    T3K_DISPATCH_R(4)
+#undef T3K_DISPATCH_R
+}
+
+}  // namespace
+
+size_t sampler_lds_bytes(int V) {
+    int npad = 2;
+    while (npad < V) npad <<= 1;
+    const size_t Vpad = (size_t)((V + 3) & ~3);
+    return Vpad * 4 + (size_t)npad * 4 + (size_t)kSampThreads * 8 + (size_t)npad * 2 + 32 * 4 + 8 * 4;
+}
+
+hipError_t launch_gemv(const GemvArgs& a, int epilogue, int wdtype, hipStream_t s) {
+    if (a.W == nullptr || a.x == nullptr || a.y == nullptr || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
+    const bool norm = (epilogue != EPI_RESID);
+    if (norm && a.ln_w == nullptr) return hipErrorInvalidValue;
+    if (epilogue == EPI_RESID && a.resid == nullptr) return hipErrorInvalidValue;
+    if (epilogue == EPI_SWIGLU && (a.N % 4)) return hipErrorInvalidValue;
+    if (epilogue == EPI_ROPE_KV) {
+        if (a.N != 3 * a.n_heads * kHeadDim || a.rowpos == nullptr || a.kcache == nullptr ||
+            a.vcache == nullptr || a.rope_cos == nullptr || a.rope_sin == nullptr || a.max_len <= 0)
+            return hipErrorInvalidValue;
+    }
+    return wdtype == 1 ? launch_gemv_w<BF16W>(a, epilogue, s) : launch_gemv_w<F32W>(a, epilogue, s);
+}
+
+hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t s) {
+    if (a.rows <= 0 || a.n_heads <= 0 || a.max_len <= 0) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)a.max_len + 16 * kHeadDim + 8) * sizeof(float);
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(a.n_heads, a.rows), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_prefill_embed(const EmbedArgs& a, hipStream_t s) {
+    if (a.rows <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(prefill_embed_kernel, dim3(a.rows), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sampler(const SamplerArgs& a, hipStream_t s) {
+    if (a.n_utt <= 0 || a.V <= 0 || a.V > 16384 || a.V > 65535) return hipErrorInvalidValue;
+    int npad = 2;
+    while (npad < a.V) npad <<= 1;
+    const size_t lds = sampler_lds_bytes(a.V);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sampler_kernel, dim3(a.n_utt), dim3(kSampThreads), lds, s, a, npad);
+    return hipGetLastError();
+}
+
+hipError_t init_device() {
+    // the sampler carves > 64 KiB of dynamic LDS; call once per device before any launch / capture
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(2048), dim3(256), 0, s, src, static_cast<uint16_t*>(dst), n);
+    return hipGetLastError();
+}
+
+}  // namespace t3k

@@ -1,0 +1,90 @@
+// Launch wrappers of the gfx950 kernels behind the t3mi C ABI (see kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+namespace t3k {
+
+enum Epilogue : int {
+    EPI_STORE = 0,    // y[r][n] = acc                                  (speech_head, R/t3.R:515)
+    EPI_RESID = 1,    // y[r][n] = resid[r][n] + acc                     (o_proj / down_proj, R/llama.R:355,360)
+    EPI_ROPE_KV = 2,  // RoPE on q,k; q -> qbuf, k,v -> cache at rowpos  (R/llama.R:227-245; src/t3_decode.cpp:134-148)
+    EPI_SWIGLU = 3,   // y[r][n] = silu(gate_n) * up_n                   (R/llama.R:305-308)
+};
+
+struct GemvArgs {
+    const void* W = nullptr;      // [N, K] row-major (row = output feature), fp32 or bf16
+    const float* x = nullptr;     // [rows, K]
+    const float* ln_w = nullptr;  // RMSNorm weight [K] (norm prologue) or nullptr
+    float eps = 1e-5f;
+    int N = 0, K = 0;
+    int rows = 0;                 // activation rows in this launch (<= 4)
+    float* y = nullptr;           // [rows, ldy]
+    const float* resid = nullptr; // [rows, ldy] (may alias y)
+    int ldy = 0;
+    // EPI_ROPE_KV
+    const int* rowpos = nullptr;  // [rows] cache position of the token in x[r]; < 0 = inactive row
+    const float* rope_cos = nullptr;  // [max_pos, 64]
+    const float* rope_sin = nullptr;
+    float* kcache = nullptr;      // this layer, these rows: [rows][H][max_len][64]
+    float* vcache = nullptr;
+    int n_heads = 0, max_len = 0;
+};
+
+struct AttnArgs {
+    const float* q = nullptr;     // [rows, H*64] (RoPE applied)
+    const float* kcache = nullptr;  // [rows][H][max_len][64]
+    const float* vcache = nullptr;
+    const int* rowpos = nullptr;  // [rows]; attends to positions 0..rowpos[r]
+    float* out = nullptr;         // [rows, H*64]
+    int rows = 0, n_heads = 0, max_len = 0;
+};
+
+struct EmbedArgs {                // token-by-token prefill input (R/t3.R:494, :505)
+    const float* const* emb_rows = nullptr;  // [rows] device pointers to [s0[r], d]
+    const int* start = nullptr;   // [rows] first prefill step at which row r is live (right-aligned prompts)
+    int t = 0;                    // prefill step
+    int d = 0, rows = 0;
+    float* x = nullptr;           // [rows, d]
+    int* rowpos = nullptr;        // [rows] out
+};
+
+struct SamplerArgs {
+    const float* logits = nullptr;  // [n_utt*rpu, V]
+    int V = 0, rpu = 1, n_utt = 0;
+    float cfg_w = 0.f, temperature = 1.f, top_p = 1.f, min_p = 0.f, penalty = 1.f;
+    int variant = 0, top_k = 0, stop_token = -1, mask_stop = 0, max_new_tokens = 0;
+    unsigned long long seed = 0;
+    uint8_t* seen = nullptr;      // [n_utt, V]
+    int* tokens = nullptr;        // [n_utt, cap]
+    int cap = 0;
+    int* n_tokens = nullptr;      // [n_utt]
+    int* done = nullptr;          // [n_utt] 0 live, 1 stop token, 2 max_new_tokens, 3 cache full
+    int* rowpos = nullptr;        // [n_utt*rpu]
+    const int* s0 = nullptr;      // [n_utt] prompt length
+    const int* forced = nullptr;  // [n_utt, n_forced] or nullptr
+    int n_forced = 0;
+    const float* emb = nullptr;      // speech_emb [V, d]
+    const float* pos_emb = nullptr;  // speech_pos_emb [max_pos, d]
+    int d = 0, max_pos = 0, max_len = 0;
+    float* x = nullptr;           // [n_utt*rpu, d] next-token embedding out
+    int* dist_ids = nullptr;      // [n_utt, dist_cap] debug (may be nullptr)
+    float* dist_probs = nullptr;
+    int* dist_n = nullptr;
+    int dist_cap = 0;
+};
+
+size_t sampler_lds_bytes(int V);
+
+// once per device (current device), before the first launch
+hipError_t init_device();
+// wdtype: 0 fp32, 1 bf16.  All launches are asynchronous on `s`.
+hipError_t launch_gemv(const GemvArgs& a, int epilogue, int wdtype, hipStream_t s);
+hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t s);
+hipError_t launch_prefill_embed(const EmbedArgs& a, hipStream_t s);
+hipError_t launch_sampler(const SamplerArgs& a, hipStream_t s);
+// fp32 -> bf16 (round to nearest even) on device, n elements
+hipError_t launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
+
+}  // namespace t3k

@@ -1,0 +1,855 @@
+// t3mi C ABI: host side of the MI355X-native T3 decoder (see include/t3mi.h).
+//
+// Owns the weights (read from the reference's unchanged safetensors layout), the RoPE tables,
+// the KV slabs and all per-session state in HBM; drives the decode step as a replayed HIP graph
+// so that a step needs no host synchronisation (the reference syncs 2-3x per token:
+// R/t3.R:530,574 ; src/t3_decode.cpp:339,361-362).
+#include "../../include/t3mi.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "safetensors.hpp"
+
+namespace {
+
+thread_local std::string g_err = "";
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(T3MI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        else p = nullptr;
+        return e;
+    }
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+struct LayerW {
+    const float* ln1 = nullptr;
+    const void* wqkv = nullptr;  // [3d, d]
+    const void* wo = nullptr;    // [d, d]
+    const float* ln2 = nullptr;
+    const void* wgu = nullptr;   // [2F, d]  gate rows then up rows
+    const void* wdown = nullptr; // [d, F]
+};
+
+struct Session {
+    int n_utt = 0, rpu = 1, rows = 0, max_len = 0, cap = 0, max_s0 = 0;
+    t3mi_params prm{};
+    std::vector<int32_t> s0;
+    DevBuf kc, vc, x, qbuf, attn, hbuf, logits, rowpos, start, emb_rows, emb_data, seen, tokens, n_tokens,
+        done, s0_dev, forced, dist_ids, dist_probs, dist_n;
+    int n_forced = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    bool graph_tried = false;
+    ~Session() {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        if (graph) (void)hipGraphDestroy(graph);
+    }
+};
+
+}  // namespace
+
+struct t3mi_model {
+    int device = 0, variant = 0, wdtype = 0;
+    int n_layers = 0, d = 0, H = 0, F = 0, V = 0, max_pos = 0;
+    float eps = 1e-5f;
+    hipStream_t stream = nullptr;
+    DevBuf wbuf, small, emb, pos_emb, rope_cos, rope_sin;
+    int rope_len = 0;
+    std::vector<LayerW> layers;
+    const float* norm_w = nullptr;
+    const void* head_w = nullptr;
+    int64_t weight_bytes = 0;
+    std::unique_ptr<Session> sess;
+    bool use_graph = true;
+};
+
+namespace {
+
+// ---- RoPE tables with Llama-3 band scaling (R/llama.R:87-152), float arithmetic as R torch ------
+void build_rope(int head_dim, int rows, std::vector<float>& cosv, std::vector<float>& sinv) {
+    const float theta = 500000.0f, factor = 8.0f;
+    const double low_freq_factor = 1.0, high_freq_factor = 4.0, old_ctx = 8192.0;
+    const int half = head_dim / 2;
+    std::vector<float> inv(half);
+    const double low_wl = old_ctx / low_freq_factor, high_wl = old_ctx / high_freq_factor;
+    for (int i = 0; i < half; ++i) {
+        const float expo = (float)(2 * i) / (float)head_dim;
+        const float f = 1.0f / powf(theta, expo);
+        const float wlf = (float)(2.0 * M_PI) / f;
+        const double wl = (double)wlf;
+        if (wl < high_wl) inv[i] = f;
+        else if (wl > low_wl) inv[i] = f / factor;
+        else {
+            const double smooth = (old_ctx / wl - low_freq_factor) / (high_freq_factor - low_freq_factor);
+            const float a = ((float)(1.0 - smooth) * f) / factor;
+            const float b = (float)smooth * f;
+            inv[i] = a + b;
+        }
+    }
+    cosv.resize((size_t)rows * head_dim);
+    sinv.resize((size_t)rows * head_dim);
+    for (int t = 0; t < rows; ++t)
+        for (int i = 0; i < half; ++i) {
+            const float fr = (float)t * inv[i];
+            const float c = cosf(fr), s = sinf(fr);
+            cosv[(size_t)t * head_dim + i] = c;
+            cosv[(size_t)t * head_dim + half + i] = c;
+            sinv[(size_t)t * head_dim + i] = s;
+            sinv[(size_t)t * head_dim + half + i] = s;
+        }
+}
+
+int ensure_rope(t3mi_model* m, int rows) {
+    if (rows <= m->rope_len) return T3MI_OK;
+    std::vector<float> c, s;
+    build_rope(64, rows, c, s);
+    HIPCHK(m->rope_cos.alloc(c.size() * 4));
+    HIPCHK(m->rope_sin.alloc(s.size() * 4));
+    HIPCHK(hipMemcpy(m->rope_cos.p, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m->rope_sin.p, s.data(), s.size() * 4, hipMemcpyHostToDevice));
+    m->rope_len = rows;
+    return T3MI_OK;
+}
+
+// ---- checkpoint -> HBM -----------------------------------------------------------------------
+struct Uploader {
+    t3mi_model* m;
+    const t3mi::SafeTensorsFile& st;
+    std::vector<float> host;
+    DevBuf stage;  // fp32 staging on device for the bf16 conversion
+
+    int get(const std::string& name, int64_t d0, int64_t d1, const t3mi::StTensor** out) {
+        const t3mi::StTensor* t = st.find(name);
+        if (!t) return fail(T3MI_ERR_IO, "checkpoint has no tensor '" + name + "'");
+        const bool ok = (d1 < 0) ? (t->shape.size() == 1 && t->shape[0] == d0)
+                                 : (t->shape.size() == 2 && t->shape[0] == d0 && t->shape[1] == d1);
+        if (!ok) return fail(T3MI_ERR_IO, "tensor '" + name + "' has an unexpected shape");
+        *out = t;
+        return T3MI_OK;
+    }
+    // fp32 copy to dst (device)
+    int put_f32(const std::string& name, int64_t d0, int64_t d1, float* dst) {
+        const t3mi::StTensor* t = nullptr;
+        int rc = get(name, d0, d1, &t);
+        if (rc) return rc;
+        const size_t n = (size_t)t->numel();
+        std::string err;
+        if (t->dtype == t3mi::StDtype::F32) {
+            HIPCHK(hipMemcpy(dst, t->data, n * 4, hipMemcpyHostToDevice));
+        } else {
+            host.resize(n);
+            if (!t3mi::SafeTensorsFile::to_f32(*t, host.data(), err)) return fail(T3MI_ERR_IO, name + ": " + err);
+            HIPCHK(hipMemcpy(dst, host.data(), n * 4, hipMemcpyHostToDevice));
+        }
+        return T3MI_OK;
+    }
+    // streamed matrix in the model's weight dtype; dst points into wbuf
+    int put_w(const std::string& name, int64_t d0, int64_t d1, void* dst) {
+        if (m->wdtype == T3MI_W_F32) return put_f32(name, d0, d1, static_cast<float*>(dst));
+        const size_t n = (size_t)d0 * (size_t)d1;
+        if (stage.bytes < n * 4) HIPCHK(stage.alloc(n * 4));
+        int rc = put_f32(name, d0, d1, stage.as<float>());
+        if (rc) return rc;
+        HIPCHK(t3k::launch_f32_to_bf16(stage.as<float>(), dst, n, nullptr));
+        HIPCHK(hipDeviceSynchronize());
+        return T3MI_OK;
+    }
+};
+
+int load_llama(t3mi_model* m, const t3mi::SafeTensorsFile& st) {
+    // infer shapes from the file (R/llama.R:20-45 for the 520M model)
+    const t3mi::StTensor* q0 = st.find("tfmr.layers.0.self_attn.q_proj.weight");
+    const t3mi::StTensor* g0 = st.find("tfmr.layers.0.mlp.gate_proj.weight");
+    const t3mi::StTensor* hd = st.find("speech_head.weight");
+    const t3mi::StTensor* pe = st.find("speech_pos_emb.emb.weight");
+    if (!q0 || !g0 || !hd || !pe || q0->shape.size() != 2 || g0->shape.size() != 2 || hd->shape.size() != 2 ||
+        pe->shape.size() != 2)
+        return fail(T3MI_ERR_IO, "checkpoint lacks the T3 Llama tensors (tfmr.layers.0.*, speech_head, speech_pos_emb)");
+    m->d = (int)q0->shape[1];
+    m->F = (int)g0->shape[0];
+    m->V = (int)hd->shape[0];
+    m->max_pos = (int)pe->shape[0];
+    if (m->d % 64 || q0->shape[0] != m->d) return fail(T3MI_ERR_IO, "hidden size must be heads*64");
+    m->H = m->d / 64;
+    int L = 0;
+    while (st.find("tfmr.layers." + std::to_string(L) + ".self_attn.q_proj.weight")) ++L;
+    m->n_layers = L;
+    const size_t d = m->d, F = m->F, V = m->V;
+    const size_t es = m->wdtype == T3MI_W_BF16 ? 2 : 4;
+    const size_t per_layer = (3 * d * d + d * d + 2 * F * d + d * F) * es;
+    const size_t total = per_layer * L + V * d * es;
+    HIPCHK(m->wbuf.alloc(total));
+    HIPCHK(m->small.alloc((2 * d * L + d) * 4));
+    HIPCHK(m->emb.alloc(V * d * 4));
+    HIPCHK(m->pos_emb.alloc((size_t)m->max_pos * d * 4));
+    m->weight_bytes = (int64_t)total + (int64_t)(2 * d * L + d) * 4;
+
+    Uploader up{m, st, {}, {}};
+    char* w = m->wbuf.as<char>();
+    float* sm = m->small.as<float>();
+    m->layers.resize(L);
+    int rc;
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "tfmr.layers." + std::to_string(l) + ".";
+        LayerW& lw = m->layers[l];
+        lw.ln1 = sm;
+        if ((rc = up.put_f32(p + "input_layernorm.weight", d, -1, sm))) return rc;
+        sm += d;
+        lw.wqkv = w;
+        if ((rc = up.put_w(p + "self_attn.q_proj.weight", d, d, w))) return rc;
+        w += d * d * es;
+        if ((rc = up.put_w(p + "self_attn.k_proj.weight", d, d, w))) return rc;
+        w += d * d * es;
+        if ((rc = up.put_w(p + "self_attn.v_proj.weight", d, d, w))) return rc;
+        w += d * d * es;
+        lw.wo = w;
+        if ((rc = up.put_w(p + "self_attn.o_proj.weight", d, d, w))) return rc;
+        w += d * d * es;
+        lw.ln2 = sm;
+        if ((rc = up.put_f32(p + "post_attention_layernorm.weight", d, -1, sm))) return rc;
+        sm += d;
+        lw.wgu = w;
+        if ((rc = up.put_w(p + "mlp.gate_proj.weight", F, d, w))) return rc;
+        w += F * d * es;
+        if ((rc = up.put_w(p + "mlp.up_proj.weight", F, d, w))) return rc;
+        w += F * d * es;
+        lw.wdown = w;
+        if ((rc = up.put_w(p + "mlp.down_proj.weight", d, F, w))) return rc;
+        w += d * F * es;
+    }
+    m->norm_w = sm;
+    if ((rc = up.put_f32("tfmr.norm.weight", d, -1, sm))) return rc;
+    m->head_w = w;
+    if ((rc = up.put_w("speech_head.weight", V, d, w))) return rc;
+    if ((rc = up.put_f32("speech_emb.weight", V, d, m->emb.as<float>()))) return rc;
+    if ((rc = up.put_f32("speech_pos_emb.emb.weight", m->max_pos, d, m->pos_emb.as<float>()))) return rc;
+    return T3MI_OK;
+}
+
+// ---- one transformer pass over the rows currently in sess->x ------------------------------------
+struct StepTimer {  // optional per-launch events for t3mi_session_profile_step
+    std::vector<hipEvent_t> ev;
+    std::vector<int> kind;
+    hipStream_t s;
+    bool on = false;
+    void mark(int k) {
+        if (!on) return;
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, s);
+        ev.push_back(e);
+        kind.push_back(k);
+    }
+};
+enum { K_SAMPLER = 0, K_QKV, K_ATTN, K_OPROJ, K_GATEUP, K_DOWN, K_HEAD, K_COUNT };
+const char* const kKindName[K_COUNT] = {"sampler", "qkv_rope_kv", "attn_decode", "o_proj_resid",
+                                        "gate_up_swiglu", "down_resid", "head"};
+
+int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
+    const int d = m->d, F = m->F, H = m->H;
+    const size_t layer_kv = (size_t)s->rows * H * s->max_len * 64;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const LayerW& lw = m->layers[l];
+        float* kc = s->kc.as<float>() + layer_kv * l;
+        float* vc = s->vc.as<float>() + layer_kv * l;
+        // K1: RMSNorm + QKV + RoPE + KV store
+        for (int r0 = 0; r0 < s->rows;) {
+            const int rem = s->rows - r0, rg = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
+            t3k::GemvArgs a;
+            a.W = lw.wqkv; a.x = s->x.as<float>() + (size_t)r0 * d; a.ln_w = lw.ln1; a.eps = m->eps;
+            a.N = 3 * d; a.K = d; a.rows = rg;
+            a.y = s->qbuf.as<float>() + (size_t)r0 * d; a.ldy = d;
+            a.rowpos = s->rowpos.as<int>() + r0;
+            a.rope_cos = m->rope_cos.as<float>(); a.rope_sin = m->rope_sin.as<float>();
+            a.kcache = kc + (size_t)r0 * H * s->max_len * 64;
+            a.vcache = vc + (size_t)r0 * H * s->max_len * 64;
+            a.n_heads = H; a.max_len = s->max_len;
+            HIPCHK(t3k::launch_gemv(a, t3k::EPI_ROPE_KV, m->wdtype, m->stream));
+            r0 += rg;
+        }
+        if (tm) tm->mark(K_QKV);
+        // K2: attention over the cache
+        {
+            t3k::AttnArgs a;
+            a.q = s->qbuf.as<float>(); a.kcache = kc; a.vcache = vc; a.rowpos = s->rowpos.as<int>();
+            a.out = s->attn.as<float>(); a.rows = s->rows; a.n_heads = H; a.max_len = s->max_len;
+            HIPCHK(t3k::launch_attn_decode(a, m->stream));
+        }
+        if (tm) tm->mark(K_ATTN);
+        // K3: o_proj + residual
+        for (int r0 = 0; r0 < s->rows;) {
+            const int rem = s->rows - r0, rg = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
+            t3k::GemvArgs a;
+            a.W = lw.wo; a.x = s->attn.as<float>() + (size_t)r0 * d; a.N = d; a.K = d; a.rows = rg;
+            a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
+            HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
+            r0 += rg;
+        }
+        if (tm) tm->mark(K_OPROJ);
+        // K4: RMSNorm + gate/up + SwiGLU
+        for (int r0 = 0; r0 < s->rows;) {
+            const int rem = s->rows - r0, rg = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
+            t3k::GemvArgs a;
+            a.W = lw.wgu; a.x = s->x.as<float>() + (size_t)r0 * d; a.ln_w = lw.ln2; a.eps = m->eps;
+            a.N = 2 * F; a.K = d; a.rows = rg;
+            a.y = s->hbuf.as<float>() + (size_t)r0 * F; a.ldy = F;
+            HIPCHK(t3k::launch_gemv(a, t3k::EPI_SWIGLU, m->wdtype, m->stream));
+            r0 += rg;
+        }
+        if (tm) tm->mark(K_GATEUP);
+        // K5: down_proj + residual
+        for (int r0 = 0; r0 < s->rows;) {
+            const int rem = s->rows - r0, rg = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
+            t3k::GemvArgs a;
+            a.W = lw.wdown; a.x = s->hbuf.as<float>() + (size_t)r0 * F; a.N = d; a.K = F; a.rows = rg;
+            a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
+            HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
+            r0 += rg;
+        }
+        if (tm) tm->mark(K_DOWN);
+    }
+    return T3MI_OK;
+}
+
+int run_head(t3mi_model* m, Session* s, StepTimer* tm) {
+    const int d = m->d;
+    for (int r0 = 0; r0 < s->rows;) {
+        const int rem = s->rows - r0, rg = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
+        t3k::GemvArgs a;
+        a.W = m->head_w; a.x = s->x.as<float>() + (size_t)r0 * d; a.ln_w = m->norm_w; a.eps = m->eps;
+        a.N = m->V; a.K = d; a.rows = rg;
+        a.y = s->logits.as<float>() + (size_t)r0 * m->V; a.ldy = m->V;
+        HIPCHK(t3k::launch_gemv(a, t3k::EPI_STORE, m->wdtype, m->stream));
+        r0 += rg;
+    }
+    if (tm) tm->mark(K_HEAD);
+    return T3MI_OK;
+}
+
+int run_sampler(t3mi_model* m, Session* s, StepTimer* tm) {
+    t3k::SamplerArgs a;
+    const t3mi_params& p = s->prm;
+    a.logits = s->logits.as<float>(); a.V = m->V; a.rpu = s->rpu; a.n_utt = s->n_utt;
+    a.cfg_w = p.cfg_weight; a.temperature = p.temperature; a.top_p = p.top_p; a.min_p = p.min_p;
+    a.penalty = p.repetition_penalty; a.variant = p.sampler; a.top_k = p.top_k; a.stop_token = p.stop_token;
+    a.mask_stop = p.mask_stop; a.max_new_tokens = p.max_new_tokens; a.seed = p.seed;
+    a.seen = s->seen.as<uint8_t>(); a.tokens = s->tokens.as<int>(); a.cap = s->cap;
+    a.n_tokens = s->n_tokens.as<int>(); a.done = s->done.as<int>(); a.rowpos = s->rowpos.as<int>();
+    a.s0 = s->s0_dev.as<int>();
+    a.forced = s->n_forced > 0 ? s->forced.as<int>() : nullptr; a.n_forced = s->n_forced;
+    a.emb = m->emb.as<float>(); a.pos_emb = m->pos_emb.as<float>(); a.d = m->d; a.max_pos = m->max_pos;
+    a.max_len = s->max_len; a.x = s->x.as<float>();
+    a.dist_ids = s->dist_ids.as<int>(); a.dist_probs = s->dist_probs.as<float>(); a.dist_n = s->dist_n.as<int>();
+    a.dist_cap = m->V;
+    HIPCHK(t3k::launch_sampler(a, m->stream));
+    if (tm) tm->mark(K_SAMPLER);
+    return T3MI_OK;
+}
+
+int run_decode_step(t3mi_model* m, Session* s, StepTimer* tm) {
+    int rc;
+    if ((rc = run_sampler(m, s, tm))) return rc;
+    if ((rc = run_layers(m, s, tm))) return rc;
+    return run_head(m, s, tm);
+}
+
+int build_graph(t3mi_model* m, Session* s) {
+    s->graph_tried = true;
+    HIPCHK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+    int rc = run_decode_step(m, s, nullptr);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(m->stream, &g);
+    if (rc) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess) return fail(T3MI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    s->graph = g;
+    HIPCHK(hipGraphInstantiate(&s->gexec, g, nullptr, nullptr, 0));
+    return T3MI_OK;
+}
+
+int need_session(t3mi_model* m) {
+    if (!m) return fail(T3MI_ERR_ARG, "null model handle");
+    if (!m->sess) return fail(T3MI_ERR_STATE, "no active session (call t3mi_session_begin first)");
+    return T3MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void t3mi_default_params(t3mi_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->max_new_tokens = 1000;
+    p->temperature = 0.8f;
+    p->cfg_weight = 0.5f;
+    p->top_p = 0.95f;
+    p->min_p = 0.05f;
+    p->repetition_penalty = 1.2f;
+    p->start_token = 6561;
+    p->stop_token = 6562;
+    p->sampler = T3MI_SAMPLER_R;
+}
+
+const char* t3mi_last_error(void) { return g_err.c_str(); }
+
+int t3mi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model** out) {
+    if (!path || !out) return fail(T3MI_ERR_ARG, "t3mi_open: null argument");
+    *out = nullptr;
+    if (variant != T3MI_VARIANT_LLAMA)
+        return fail(T3MI_ERR_ARG, "t3mi_open: only T3MI_VARIANT_LLAMA is implemented in this build");
+    if (wdtype != T3MI_W_F32 && wdtype != T3MI_W_BF16) return fail(T3MI_ERR_ARG, "t3mi_open: bad wdtype");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(T3MI_ERR_HIP, "t3mi_open: no HIP device visible (the MI355X path has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(T3MI_ERR_ARG, "t3mi_open: device index out of range");
+    HIPCHK(hipSetDevice(device));
+    t3mi::SafeTensorsFile st;
+    std::string err;
+    if (!st.open(path, err)) return fail(T3MI_ERR_IO, err);
+    std::unique_ptr<t3mi_model> m(new t3mi_model());
+    m->device = device;
+    m->variant = variant;
+    m->wdtype = wdtype;
+    const char* g = std::getenv("T3MI_GRAPH");
+    m->use_graph = !(g && g[0] == '0');
+    HIPCHK(t3k::init_device());
+    HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    int rc = load_llama(m.get(), st);
+    if (rc) {
+        (void)hipStreamDestroy(m->stream);
+        return rc;
+    }
+    if (t3k::sampler_lds_bytes(m->V) > 160 * 1024 || m->V > 16384) {
+        (void)hipStreamDestroy(m->stream);
+        return fail(T3MI_ERR_IO, "vocabulary too large for the single-workgroup sampler");
+    }
+    HIPCHK(hipDeviceSynchronize());
+    *out = m.release();
+    return T3MI_OK;
+}
+
+int t3mi_close(t3mi_model* m) {
+    if (!m) return T3MI_OK;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    m->sess.reset();
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return T3MI_OK;
+}
+
+int t3mi_get_info(const t3mi_model* m, t3mi_info* info) {
+    if (!m || !info) return fail(T3MI_ERR_ARG, "t3mi_get_info: null argument");
+    info->variant = m->variant;
+    info->n_layers = m->n_layers;
+    info->d_model = m->d;
+    info->n_heads = m->H;
+    info->head_dim = 64;
+    info->d_ff = m->F;
+    info->vocab = m->V;
+    info->max_pos = m->max_pos;
+    info->wdtype = m->wdtype;
+    info->device = m->device;
+    info->weight_bytes = m->weight_bytes;
+    return T3MI_OK;
+}
+
+void* t3mi_stream(t3mi_model* m) { return m ? (void*)m->stream : nullptr; }
+
+int t3mi_session_end(t3mi_model* m) {
+    if (!m) return fail(T3MI_ERR_ARG, "null model handle");
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    m->sess.reset();
+    return T3MI_OK;
+}
+
+int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* embeds, const int32_t* s0,
+                       const t3mi_params* p, int embeds_on_device) {
+    if (!m || !embeds || !s0 || !p) return fail(T3MI_ERR_ARG, "t3mi_session_begin: null argument");
+    if (n_utt <= 0) return fail(T3MI_ERR_ARG, "t3mi_session_begin: n_utt must be positive");
+    if (rpu != 1 && rpu != 2) return fail(T3MI_ERR_ARG, "t3mi_session_begin: rows per utterance must be 1 or 2");
+    if (p->cfg_weight > 0.f && rpu != 2)
+        return fail(T3MI_ERR_ARG, "cfg_weight > 0 needs the cond/uncond row pair (rows = 2, R/t3.R:480-491)");
+    if (p->max_new_tokens <= 0) return fail(T3MI_ERR_ARG, "max_new_tokens must be positive");
+    if (p->sampler != T3MI_SAMPLER_R && p->sampler != T3MI_SAMPLER_CPP)
+        return fail(T3MI_ERR_ARG, "sampler must be T3MI_SAMPLER_R or T3MI_SAMPLER_CPP for the Llama variant");
+    if (!(p->temperature > 0.f)) return fail(T3MI_ERR_ARG, "temperature must be > 0");
+    if (!(p->repetition_penalty > 0.f)) return fail(T3MI_ERR_ARG, "repetition_penalty must be > 0");
+    if (p->stop_token < 0 || p->stop_token >= m->V) return fail(T3MI_ERR_ARG, "stop_token outside the vocabulary");
+    HIPCHK(hipSetDevice(m->device));
+    if (m->sess) t3mi_session_end(m);
+
+    std::unique_ptr<Session> s(new Session());
+    s->n_utt = n_utt;
+    s->rpu = rpu;
+    s->rows = n_utt * rpu;
+    s->prm = *p;
+    s->s0.assign(s0, s0 + n_utt);
+    int max_s0 = 0, min_s0 = 1 << 30;
+    for (int u = 0; u < n_utt; ++u) {
+        if (s0[u] <= 0) return fail(T3MI_ERR_ARG, "prompt length must be positive");
+        if (!embeds[u]) return fail(T3MI_ERR_ARG, "null prompt pointer");
+        max_s0 = std::max(max_s0, s0[u]);
+        min_s0 = std::min(min_s0, s0[u]);
+    }
+    s->max_s0 = max_s0;
+    int max_new = p->max_new_tokens;
+    if (p->max_cache_len > 0) {
+        // t3_inference_cpp: max_gen_tokens = min(max_new_tokens, max_cache_len - cond_len - 1)  (R/t3.R:996)
+        const int room = p->max_cache_len - max_s0 - 1;
+        if (room <= 0) return fail(T3MI_ERR_ARG, "prompt does not fit max_cache_len (R/llama_traced.R:343-345)");
+        max_new = std::min(max_new, room);
+    }
+    if (max_new + 1 > m->max_pos) max_new = m->max_pos - 1;  // learned speech pos-emb rows (R/t3.R:349)
+    s->prm.max_new_tokens = max_new;
+    s->cap = max_new;
+    s->max_len = ((p->max_cache_len > 0 ? p->max_cache_len : max_s0 + max_new) + 7) & ~7;
+    int rc = ensure_rope(m, s->max_len);
+    if (rc) return rc;
+
+    const size_t d = m->d, F = m->F, V = m->V, rows = s->rows, U = n_utt;
+    const size_t kv = (size_t)m->n_layers * rows * m->H * s->max_len * 64 * 4;
+    HIPCHK(s->kc.alloc(kv));
+    HIPCHK(s->vc.alloc(kv));
+    HIPCHK(s->x.alloc(rows * d * 4));
+    HIPCHK(s->qbuf.alloc(rows * d * 4));
+    HIPCHK(s->attn.alloc(rows * d * 4));
+    HIPCHK(s->hbuf.alloc(rows * F * 4));
+    HIPCHK(s->logits.alloc(rows * V * 4));
+    HIPCHK(s->rowpos.alloc(rows * 4));
+    HIPCHK(s->start.alloc(rows * 4));
+    HIPCHK(s->emb_rows.alloc(rows * sizeof(void*)));
+    HIPCHK(s->seen.alloc(U * V));
+    HIPCHK(s->tokens.alloc(U * (size_t)s->cap * 4));
+    HIPCHK(s->n_tokens.alloc(U * 4));
+    HIPCHK(s->done.alloc(U * 4));
+    HIPCHK(s->s0_dev.alloc(U * 4));
+    HIPCHK(s->dist_ids.alloc(U * V * 4));
+    HIPCHK(s->dist_probs.alloc(U * V * 4));
+    HIPCHK(s->dist_n.alloc(U * 4));
+    hipStream_t st = m->stream;
+    // create_kv_cache zero-fills the slabs (R/llama_traced.R:276-283)
+    HIPCHK(hipMemsetAsync(s->kc.p, 0, kv, st));
+    HIPCHK(hipMemsetAsync(s->vc.p, 0, kv, st));
+    HIPCHK(hipMemsetAsync(s->x.p, 0, rows * d * 4, st));
+    HIPCHK(hipMemsetAsync(s->qbuf.p, 0, rows * d * 4, st));
+    HIPCHK(hipMemsetAsync(s->attn.p, 0, rows * d * 4, st));
+    HIPCHK(hipMemsetAsync(s->hbuf.p, 0, rows * F * 4, st));
+    HIPCHK(hipMemsetAsync(s->logits.p, 0, rows * V * 4, st));
+    HIPCHK(hipMemsetAsync(s->seen.p, 0, U * V, st));
+    HIPCHK(hipMemsetAsync(s->tokens.p, 0, U * (size_t)s->cap * 4, st));
+    HIPCHK(hipMemsetAsync(s->n_tokens.p, 0, U * 4, st));
+    HIPCHK(hipMemsetAsync(s->done.p, 0, U * 4, st));
+    HIPCHK(hipMemsetAsync(s->dist_n.p, 0, U * 4, st));
+
+    // prompts: right-align so every utterance finishes its prefill at the same step
+    std::vector<const float*> row_ptr(rows);
+    std::vector<int32_t> start(rows);
+    if (embeds_on_device) {
+        for (int u = 0; u < n_utt; ++u)
+            for (int r = 0; r < rpu; ++r) {
+                row_ptr[u * rpu + r] = embeds[u] + (size_t)r * s0[u] * d;
+                start[u * rpu + r] = max_s0 - s0[u];
+            }
+    } else {
+        size_t tot = 0;
+        for (int u = 0; u < n_utt; ++u) tot += (size_t)rpu * s0[u] * d;
+        HIPCHK(s->emb_data.alloc(tot * 4));
+        size_t off = 0;
+        for (int u = 0; u < n_utt; ++u) {
+            const size_t n = (size_t)rpu * s0[u] * d;
+            HIPCHK(hipMemcpyAsync(s->emb_data.as<float>() + off, embeds[u], n * 4, hipMemcpyHostToDevice, st));
+            for (int r = 0; r < rpu; ++r) {
+                row_ptr[u * rpu + r] = s->emb_data.as<float>() + off + (size_t)r * s0[u] * d;
+                start[u * rpu + r] = max_s0 - s0[u];
+            }
+            off += n;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(s->emb_rows.p, row_ptr.data(), rows * sizeof(void*), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->start.p, start.data(), rows * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->s0_dev.p, s->s0.data(), U * 4, hipMemcpyHostToDevice, st));
+    if (p->sampler == T3MI_SAMPLER_R && p->repetition_penalty != 1.0f) {
+        // Q3: generated_ids starts as the raw BOS id used as a 1-based column => 0-based column BOS-1
+        // is penalised from the first step on (R/t3.R:509, 530-531)
+        const int col = p->start_token - 1;
+        if (col >= 0 && col < m->V)
+            for (int u = 0; u < n_utt; ++u)
+                HIPCHK(hipMemsetAsync(s->seen.as<uint8_t>() + (size_t)u * V + col, 1, 1, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));  // row_ptr/start are stack-local
+
+    // prefill, one prompt position per pass (decode kernels; the batched prefill GEMM is a later row)
+    for (int t = 0; t < max_s0; ++t) {
+        t3k::EmbedArgs e;
+        e.emb_rows = s->emb_rows.as<const float*>();
+        e.start = s->start.as<int>();
+        e.t = t; e.d = m->d; e.rows = s->rows;
+        e.x = s->x.as<float>(); e.rowpos = s->rowpos.as<int>();
+        HIPCHK(t3k::launch_prefill_embed(e, st));
+        if ((rc = run_layers(m, s.get(), nullptr))) return rc;
+    }
+    if ((rc = run_head(m, s.get(), nullptr))) return rc;
+    HIPCHK(hipStreamSynchronize(st));
+    m->sess = std::move(s);
+    return T3MI_OK;
+}
+
+int t3mi_session_force(t3mi_model* m, const int32_t* forced, int n_forced) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    Session* s = m->sess.get();
+    if (!forced || n_forced <= 0) return fail(T3MI_ERR_ARG, "t3mi_session_force: empty token list");
+    if (s->gexec) return fail(T3MI_ERR_STATE, "t3mi_session_force must precede the first decode call");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(s->forced.alloc((size_t)s->n_utt * n_forced * 4));
+    HIPCHK(hipMemcpy(s->forced.p, forced, (size_t)s->n_utt * n_forced * 4, hipMemcpyHostToDevice));
+    s->n_forced = n_forced;
+    return T3MI_OK;
+}
+
+int t3mi_session_decode(t3mi_model* m, int n_steps) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    if (n_steps <= 0) return fail(T3MI_ERR_ARG, "n_steps must be positive");
+    Session* s = m->sess.get();
+    HIPCHK(hipSetDevice(m->device));
+    if (m->use_graph && !s->graph_tried) {
+        if ((rc = build_graph(m, s))) return rc;
+    }
+    for (int i = 0; i < n_steps; ++i) {
+        if (s->gexec) HIPCHK(hipGraphLaunch(s->gexec, m->stream));
+        else if ((rc = run_decode_step(m, s, nullptr))) return rc;
+    }
+    return T3MI_OK;
+}
+
+int t3mi_session_decode_timed(t3mi_model* m, int n_steps, float* ms) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    if (!ms) return fail(T3MI_ERR_ARG, "null ms");
+    HIPCHK(hipSetDevice(m->device));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, m->stream));
+    rc = t3mi_session_decode(m, n_steps);
+    if (!rc) {
+        hipError_t e = hipEventRecord(e1, m->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1);
+        if (e != hipSuccess) rc = fail(T3MI_ERR_HIP, std::string("event timing: ") + hipGetErrorString(e));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int t3mi_session_sync(t3mi_model* m) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return T3MI_OK;
+}
+
+int t3mi_session_status(t3mi_model* m, int32_t* n_tokens, int32_t* done) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    Session* s = m->sess.get();
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (n_tokens) HIPCHK(hipMemcpy(n_tokens, s->n_tokens.p, (size_t)s->n_utt * 4, hipMemcpyDeviceToHost));
+    if (done) HIPCHK(hipMemcpy(done, s->done.p, (size_t)s->n_utt * 4, hipMemcpyDeviceToHost));
+    return T3MI_OK;
+}
+
+int t3mi_session_tokens(t3mi_model* m, int utt, int32_t* out, int32_t cap, int32_t* n_out) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    Session* s = m->sess.get();
+    if (utt < 0 || utt >= s->n_utt || !out || !n_out) return fail(T3MI_ERR_ARG, "t3mi_session_tokens: bad argument");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    int32_t n = 0;
+    HIPCHK(hipMemcpy(&n, s->n_tokens.as<int>() + utt, 4, hipMemcpyDeviceToHost));
+    n = std::min(n, (int32_t)s->cap);
+    const int32_t k = std::min(n, cap);
+    if (k > 0) HIPCHK(hipMemcpy(out, s->tokens.as<int>() + (size_t)utt * s->cap, (size_t)k * 4, hipMemcpyDeviceToHost));
+    *n_out = k;
+    return T3MI_OK;
+}
+
+int t3mi_session_logits(t3mi_model* m, float* out) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    if (!out) return fail(T3MI_ERR_ARG, "null out");
+    Session* s = m->sess.get();
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(out, s->logits.p, (size_t)s->rows * m->V * 4, hipMemcpyDeviceToHost));
+    return T3MI_OK;
+}
+
+int t3mi_session_dist(t3mi_model* m, int utt, int32_t* ids, float* probs, int32_t cap, int32_t* n) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    Session* s = m->sess.get();
+    if (utt < 0 || utt >= s->n_utt || !ids || !probs || !n) return fail(T3MI_ERR_ARG, "t3mi_session_dist: bad argument");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    int32_t k = 0;
+    HIPCHK(hipMemcpy(&k, s->dist_n.as<int>() + utt, 4, hipMemcpyDeviceToHost));
+    *n = k;
+    k = std::min(std::min(k, cap), (int32_t)m->V);
+    if (k > 0) {
+        HIPCHK(hipMemcpy(ids, s->dist_ids.as<int>() + (size_t)utt * m->V, (size_t)k * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(probs, s->dist_probs.as<float>() + (size_t)utt * m->V, (size_t)k * 4, hipMemcpyDeviceToHost));
+    }
+    return T3MI_OK;
+}
+
+int t3mi_session_profile_step(t3mi_model* m, t3mi_kstat* stats, int cap, int* n_stats) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    if (!stats || !n_stats || cap < K_COUNT) return fail(T3MI_ERR_ARG, "t3mi_session_profile_step: need room for 7 entries");
+    Session* s = m->sess.get();
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    // cache lengths before the step, for the attention byte count
+    std::vector<int32_t> ntok(s->n_utt), done(s->n_utt);
+    HIPCHK(hipMemcpy(ntok.data(), s->n_tokens.p, (size_t)s->n_utt * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(done.data(), s->done.p, (size_t)s->n_utt * 4, hipMemcpyDeviceToHost));
+    StepTimer tm;
+    tm.s = m->stream;
+    tm.on = true;
+    tm.mark(-1);
+    rc = run_decode_step(m, s, &tm);
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(m->stream);
+        if (e != hipSuccess) rc = fail(T3MI_ERR_HIP, hipGetErrorString(e));
+    }
+    if (!rc) {
+        const double es = m->wdtype == T3MI_W_BF16 ? 2.0 : 4.0;
+        const double d = m->d, F = m->F, V = m->V;
+        double kvb = 0;
+        for (int u = 0; u < s->n_utt; ++u)
+            if (!done[u]) kvb += (double)s->rpu * 2.0 * d * (s->s0[u] + ntok[u] + 1) * 4.0;
+        for (int k = 0; k < K_COUNT; ++k) {
+            std::memset(&stats[k], 0, sizeof(t3mi_kstat));
+            std::snprintf(stats[k].name, sizeof(stats[k].name), "%s", kKindName[k]);
+        }
+        for (size_t i = 1; i < tm.ev.size(); ++i) {
+            float us = 0.f;
+            (void)hipEventElapsedTime(&us, tm.ev[i - 1], tm.ev[i]);
+            t3mi_kstat& ks = stats[tm.kind[i]];
+            ks.launches += 1;
+            ks.total_us += us * 1000.f;
+        }
+        const double L = m->n_layers;
+        stats[K_QKV].bytes = L * 3 * d * d * es;
+        stats[K_ATTN].bytes = L * kvb;
+        stats[K_OPROJ].bytes = L * d * d * es;
+        stats[K_GATEUP].bytes = L * 2 * F * d * es;
+        stats[K_DOWN].bytes = L * d * F * es;
+        stats[K_HEAD].bytes = V * d * es + (double)s->rows * V * 4;
+        stats[K_SAMPLER].bytes = (double)s->rows * V * 4;
+        *n_stats = K_COUNT;
+    }
+    for (hipEvent_t e : tm.ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+int t3mi_generate_batch(t3mi_model* m, int n_utt, int rpu, const float* const* embeds, const int32_t* s0,
+                        const t3mi_params* p, int32_t* out, int32_t cap, int32_t* n_out) {
+    if (!out || !n_out) return fail(T3MI_ERR_ARG, "t3mi_generate_batch: null output");
+    int rc = t3mi_session_begin(m, n_utt, rpu, embeds, s0, p, 0);
+    if (rc) return rc;
+    Session* s = m->sess.get();
+    const int max_new = s->prm.max_new_tokens;
+    if (cap < max_new) {
+        t3mi_session_end(m);
+        return fail(T3MI_ERR_ARG, "output capacity is smaller than max_new_tokens");
+    }
+    std::vector<int32_t> ntok(n_utt), done(n_utt);
+    int issued = 0;
+    bool all_done = false;
+    while (!all_done && issued < max_new) {
+        const int chunk = std::min(32, max_new - issued);
+        if ((rc = t3mi_session_decode(m, chunk))) break;
+        issued += chunk;
+        if ((rc = t3mi_session_status(m, ntok.data(), done.data()))) break;
+        all_done = true;
+        for (int u = 0; u < n_utt; ++u) all_done = all_done && done[u] != 0;
+    }
+    int warn = T3MI_OK;
+    if (!rc) {
+        for (int u = 0; u < n_utt && !rc; ++u) {
+            rc = t3mi_session_tokens(m, u, out + (size_t)u * cap, cap, &n_out[u]);
+            if (done[u] == 3) warn = T3MI_WARN_CACHE_FULL;
+        }
+    }
+    std::string keep = g_err;
+    t3mi_session_end(m);
+    if (rc) {
+        g_err = keep;
+        return rc;
+    }
+    if (warn) g_err = "KV cache full, generation stopped (src/t3_decode.cpp:394-397)";
+    return warn;
+}
+
+int t3mi_generate(t3mi_model* m, const float* embeds, int rows, int s0, const t3mi_params* p, int32_t* out,
+                  int32_t cap, int32_t* n_out) {
+    const float* ptrs[1] = {embeds};
+    const int32_t s0v[1] = {s0};
+    return t3mi_generate_batch(m, 1, rows, ptrs, s0v, p, out, cap, n_out);
+}
+
+}  // extern "C"

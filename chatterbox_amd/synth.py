@@ -33,8 +33,8 @@ class T3Dims:
 
 FULL = T3Dims()
 # reduced shape for committed goldens / fast CPU parity (head_dim stays 64)
-TINY = T3Dims(hidden_size=256, intermediate_size=1024, num_hidden_layers=2,
-              num_attention_heads=4, head_dim=64, speech_vocab=1000, max_speech_pos=600,
+TINY = T3Dims(hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
+              num_attention_heads=8, head_dim=64, speech_vocab=1000, max_speech_pos=600,
               start_speech_token=990, stop_speech_token=991)
 
 

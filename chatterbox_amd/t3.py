@@ -1,0 +1,249 @@
+"""Host-side mirror of the reference's T3 interface over the t3mi C ABI.
+
+The reference's host language is R (`t3_inference`, `t3_inference_cpp`,
+R/t3.R:461-605, 932-1050); R is not installed in the build image, so this module
+is the Python stand-in that keeps the same function names, argument names,
+defaults, return convention (0-indexed speech-token ids) and error behaviour.  The
+R glue that binds the same C entry points lives in r-package/ (INTEGRATION.md).
+
+Until the prompt builder lands, the functions take the output of
+`prepare_input_embeds` (R/t3.R:372-403) -- float32 `[rows, S0, 1024]`, rows = 2
+with CFG (cond, uncond) -- instead of `(cond, text_tokens)`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["T3Model", "load_t3", "t3_inference", "t3_inference_cpp", "t3_inference_batch", "Session"]
+
+_DT = {"f32": _lib.W_F32, "fp32": _lib.W_F32, "float32": _lib.W_F32, "bf16": _lib.W_BF16,
+       "bfloat16": _lib.W_BF16}
+
+
+class T3Model:
+    """Handle to weights resident on one MI355X (replaces the R `t3_model` object for
+    the decode path: load_t3_weights R/t3.R:1061-1145 + .get_cpp_weights :884-912)."""
+
+    def __init__(self, path: str, device: int = 0, dtype: str = "f32", variant: int = _lib.VARIANT_LLAMA,
+                 start_speech_token: int = 6561, stop_speech_token: int = 6562):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.t3mi_open(path.encode(), variant, int(device), _DT[dtype], C.byref(h)))
+        self._h = h
+        info = _lib.Info()
+        _lib.check(self._lib.t3mi_get_info(self._h, C.byref(info)))
+        self.info = info
+        self.d_model, self.vocab, self.n_layers = info.d_model, info.vocab, info.n_layers
+        # R/t3.R:19-20 (overridable for reduced-vocabulary test checkpoints)
+        self.start_speech_token, self.stop_speech_token = int(start_speech_token), int(stop_speech_token)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.t3mi_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def load_t3(path: str, device: int = 0, dtype: str = "f32", **kw) -> T3Model:
+    return T3Model(path, device, dtype, **kw)
+
+
+def _params(model: T3Model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
+            sampler, max_cache_len=0, seed=0, mask_stop=False) -> _lib.Params:
+    p = _lib.Params()
+    model._lib.t3mi_default_params(C.byref(p))
+    p.max_new_tokens = int(max_new_tokens)
+    p.temperature = float(temperature)
+    p.cfg_weight = float(cfg_weight)
+    p.top_p = float(top_p)
+    p.min_p = float(min_p)
+    p.repetition_penalty = float(repetition_penalty)
+    p.start_token = int(model.start_speech_token)
+    p.stop_token = int(model.stop_speech_token)
+    p.sampler = int(sampler)
+    p.max_cache_len = int(max_cache_len)
+    p.mask_stop = 1 if mask_stop else 0
+    p.seed = int(seed)
+    return p
+
+
+def _as_embeds(model: T3Model, embeds, cfg_weight: float) -> np.ndarray:
+    e = np.ascontiguousarray(embeds, dtype=np.float32)
+    if e.ndim == 2:
+        e = e[None]
+    if e.ndim != 3 or e.shape[2] != model.d_model:
+        raise ValueError(f"embeds must be [rows, S0, {model.d_model}], got {e.shape}")
+    if cfg_weight > 0.0 and e.shape[0] != 2:
+        raise ValueError("cfg_weight > 0 needs the cond/uncond pair: embeds[2, S0, d] (R/t3.R:480-491)")
+    if cfg_weight <= 0.0 and e.shape[0] != 1:
+        e = e[:1].copy()       # R/t3.R:523: only the first row is used without CFG
+    return e
+
+
+def t3_inference(model: T3Model, embeds, max_new_tokens: int = 1000, temperature: float = 0.8,
+                 cfg_weight: float = 0.5, top_p: float = 0.95, min_p: float = 0.05,
+                 repetition_penalty: float = 1.2, seed: int = 0) -> np.ndarray:
+    """R/t3.R:461-605.  Returns 0-indexed speech tokens, INCLUDING the stop token if it
+    was sampled (Q14).  `top_p = 0` is the deterministic (greedy) mode (Q6)."""
+    e = _as_embeds(model, embeds, cfg_weight)
+    p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
+                _lib.SAMPLER_R, 0, seed)
+    out = np.zeros(int(max_new_tokens), dtype=np.int32)
+    n = C.c_int32(0)
+    _lib.check(model._lib.t3mi_generate(
+        model._h, e.ctypes.data_as(C.POINTER(C.c_float)), e.shape[0], e.shape[1], C.byref(p),
+        out.ctypes.data_as(C.POINTER(C.c_int32)), out.shape[0], C.byref(n)))
+    return out[: n.value].astype(np.int64)
+
+
+def t3_inference_cpp(model: T3Model, embeds, max_new_tokens: int = 1000, temperature: float = 0.8,
+                     cfg_weight: float = 0.5, top_p: float = 0.95, min_p: float = 0.05,
+                     repetition_penalty: float = 1.2, max_cache_len: int = 350, seed: int = 0) -> np.ndarray:
+    """R/t3.R:932-1050 (backend = "cpp"): 350-slot cache, cpp sampling rule (Q3/Q4),
+    result stripped at the first stop token (R/t3.R:1039-1045)."""
+    e = _as_embeds(model, embeds, cfg_weight)
+    p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
+                _lib.SAMPLER_CPP, max_cache_len, seed)
+    out = np.zeros(int(max_new_tokens), dtype=np.int32)
+    n = C.c_int32(0)
+    rc = _lib.check(model._lib.t3mi_generate(
+        model._h, e.ctypes.data_as(C.POINTER(C.c_float)), e.shape[0], e.shape[1], C.byref(p),
+        out.ctypes.data_as(C.POINTER(C.c_int32)), out.shape[0], C.byref(n)))
+    if rc == _lib.WARN_CACHE_FULL:
+        import warnings
+        warnings.warn("KV cache full, stopping generation")       # src/t3_decode.cpp:395
+    toks = out[: n.value].astype(np.int64)
+    stop = np.nonzero(toks == model.stop_speech_token)[0]
+    if stop.size:
+        toks = toks[: stop[0]]
+    return toks
+
+
+def t3_inference_batch(model: T3Model, embeds_list: Sequence, max_new_tokens: int = 1000,
+                       temperature: float = 0.8, cfg_weight: float = 0.5, top_p: float = 0.95,
+                       min_p: float = 0.05, repetition_penalty: float = 1.2, seed: int = 0,
+                       mask_stop: bool = False) -> List[np.ndarray]:
+    """Independent utterances decoded together (the batch axis tts_chunked leaves serial,
+    R/tts.R:462-474).  Same per-utterance semantics as t3_inference."""
+    es = [_as_embeds(model, e, cfg_weight) for e in embeds_list]
+    rpu = es[0].shape[0]
+    n_utt = len(es)
+    p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
+                _lib.SAMPLER_R, 0, seed, mask_stop)
+    ptrs = (C.c_void_p * n_utt)(*[e.ctypes.data for e in es])
+    s0 = (C.c_int32 * n_utt)(*[e.shape[1] for e in es])
+    out = np.zeros((n_utt, int(max_new_tokens)), dtype=np.int32)
+    n_out = (C.c_int32 * n_utt)()
+    _lib.check(model._lib.t3mi_generate_batch(
+        model._h, n_utt, rpu, ptrs, s0, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_int32)),
+        out.shape[1], n_out))
+    return [out[u, : n_out[u]].astype(np.int64) for u in range(n_utt)]
+
+
+class Session:
+    """The decode loop in pieces (t3mi_session_*): prefill once, then enqueue steps.
+    Used by bench.py (timed region = decode steps only) and by the parity tests
+    (raw logits / filtered distribution of each step, teacher forcing)."""
+
+    def __init__(self, model: T3Model, embeds_list: Sequence, max_new_tokens: int = 1000,
+                 temperature: float = 0.8, cfg_weight: float = 0.5, top_p: float = 0.95,
+                 min_p: float = 0.05, repetition_penalty: float = 1.2, sampler: int = _lib.SAMPLER_R,
+                 max_cache_len: int = 0, seed: int = 0, mask_stop: bool = False,
+                 forced: Optional[np.ndarray] = None, device_ptrs: Optional[Sequence[Tuple[int, int]]] = None):
+        self.model = model
+        L = model._lib
+        p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
+                    sampler, max_cache_len, seed, mask_stop)
+        if device_ptrs is not None:
+            # [(device_address, s0)] of prompts already resident in HBM, each [rpu, s0, d] float32
+            self.n_utt = len(device_ptrs)
+            self.rpu = 2 if cfg_weight > 0 else 1
+            ptrs = (C.c_void_p * self.n_utt)(*[int(a) for a, _ in device_ptrs])
+            s0 = (C.c_int32 * self.n_utt)(*[int(s) for _, s in device_ptrs])
+            on_dev = 1
+            self._keep = None
+        else:
+            es = [_as_embeds(model, e, cfg_weight) for e in embeds_list]
+            self._keep = es
+            self.n_utt, self.rpu = len(es), es[0].shape[0]
+            ptrs = (C.c_void_p * self.n_utt)(*[e.ctypes.data for e in es])
+            s0 = (C.c_int32 * self.n_utt)(*[e.shape[1] for e in es])
+            on_dev = 0
+        _lib.check(L.t3mi_session_begin(model._h, self.n_utt, self.rpu, ptrs, s0, C.byref(p), on_dev))
+        self.max_new_tokens = int(max_new_tokens)
+        if forced is not None:
+            f = np.ascontiguousarray(forced, dtype=np.int32).reshape(self.n_utt, -1)
+            _lib.check(L.t3mi_session_force(model._h, f.ctypes.data_as(C.POINTER(C.c_int32)), f.shape[1]))
+
+    def decode(self, n_steps: int = 1):
+        _lib.check(self.model._lib.t3mi_session_decode(self.model._h, int(n_steps)))
+
+    def decode_timed(self, n_steps: int) -> float:
+        ms = C.c_float(0)
+        _lib.check(self.model._lib.t3mi_session_decode_timed(self.model._h, int(n_steps), C.byref(ms)))
+        return float(ms.value)
+
+    def sync(self):
+        _lib.check(self.model._lib.t3mi_session_sync(self.model._h))
+
+    def status(self):
+        n = (C.c_int32 * self.n_utt)()
+        d = (C.c_int32 * self.n_utt)()
+        _lib.check(self.model._lib.t3mi_session_status(self.model._h, n, d))
+        return np.array(n[:], dtype=np.int64), np.array(d[:], dtype=np.int64)
+
+    def tokens(self, utt: int = 0) -> np.ndarray:
+        out = np.zeros(self.max_new_tokens, dtype=np.int32)
+        n = C.c_int32(0)
+        _lib.check(self.model._lib.t3mi_session_tokens(
+            self.model._h, utt, out.ctypes.data_as(C.POINTER(C.c_int32)), out.shape[0], C.byref(n)))
+        return out[: n.value].astype(np.int64)
+
+    def logits(self) -> np.ndarray:
+        out = np.zeros((self.n_utt * self.rpu, self.model.vocab), dtype=np.float32)
+        _lib.check(self.model._lib.t3mi_session_logits(self.model._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def dist(self, utt: int = 0):
+        V = self.model.vocab
+        ids = np.zeros(V, dtype=np.int32)
+        pr = np.zeros(V, dtype=np.float32)
+        n = C.c_int32(0)
+        _lib.check(self.model._lib.t3mi_session_dist(
+            self.model._h, utt, ids.ctypes.data_as(C.POINTER(C.c_int32)),
+            pr.ctypes.data_as(C.POINTER(C.c_float)), V, C.byref(n)))
+        return ids[: n.value].astype(np.int64), pr[: n.value].copy()
+
+    def profile_step(self):
+        st = (_lib.KStat * 16)()
+        n = C.c_int(0)
+        _lib.check(self.model._lib.t3mi_session_profile_step(self.model._h, st, 16, C.byref(n)))
+        return [dict(name=st[i].name.decode(), launches=int(st[i].launches), total_us=float(st[i].total_us),
+                     bytes=float(st[i].bytes)) for i in range(n.value)]
+
+    def end(self):
+        if self.model is not None and self.model._h:
+            self.model._lib.t3mi_session_end(self.model._h)
+        self.model = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.end()

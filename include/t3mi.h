@@ -1,0 +1,148 @@
+/* t3mi -- MI355X-native T3 speech-token decoder: C ABI (plain pointers and sizes).
+ *
+ * Drop-in boundary for chatterbox's T3 decode path.  The reference crosses from R to
+ * native code exactly once per utterance:
+ *     .Call("cpp_t3_decode", <11 SEXP>, PACKAGE = "chatterbox")      R/t3.R:1010-1036
+ *     SEXP cpp_t3_decode(SEXP x 11)                                  src/t3_decode.cpp:207-219
+ * Its tensor arguments are R-torch external pointers (src/t3_decode.cpp:26-32) that are
+ * unusable without libtorch, so this ABI takes (i) a model handle opened from the
+ * UNCHANGED safetensors file, (ii) the prompt embeddings as a plain float array and
+ * (iii) the same decode parameters as the reference's named config list
+ * (R/t3.R:1022-1034).  The R glue that binds these entry points is r-package/src/r_glue.c;
+ * INTEGRATION.md shows the binding.
+ *
+ * All functions return T3MI_OK (0) or a negative status; t3mi_last_error() gives the
+ * text.  Nothing throws across this boundary.  One model handle = one GPU = one HIP
+ * stream; calls on one handle are not re-entrant (the reference is single-threaded too,
+ * SURVEY §8b "Threading").
+ */
+#ifndef T3MI_H
+#define T3MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T3MI_OK 0
+#define T3MI_ERR_ARG (-1)     /* bad argument (Rf_error in the reference glue)            */
+#define T3MI_ERR_IO (-2)      /* checkpoint missing / malformed / tensor shape mismatch   */
+#define T3MI_ERR_HIP (-3)     /* HIP runtime failure (no device, OOM, launch error)       */
+#define T3MI_ERR_STATE (-4)   /* call out of order (no active session, ...)               */
+#define T3MI_WARN_CACHE_FULL 1 /* generation stopped: KV cache full (src/t3_decode.cpp:394-397) */
+
+/* model variants: t3_model (Llama-520M, R/t3.R:326-442) / t3_model_turbo (GPT-2, R/t3.R:1420-1478) */
+#define T3MI_VARIANT_LLAMA 0
+#define T3MI_VARIANT_TURBO 1
+
+/* storage type of the streamed weight matrices (arithmetic is always fp32 accumulate) */
+#define T3MI_W_F32 0
+#define T3MI_W_BF16 1
+
+/* sampling-tail rule (the two reference backends differ) */
+#define T3MI_SAMPLER_R 0      /* R/t3.R:529-567   : BOS-quirk penalty column, drops crossing token */
+#define T3MI_SAMPLER_CPP 1    /* src/t3_decode.cpp:318-362 : empty seen set, keeps crossing token  */
+#define T3MI_SAMPLER_TURBO 2  /* R/t3.R:1688-1742 : sign-aware penalty, top-k, top-p on logits     */
+
+typedef struct t3mi_model t3mi_model;
+
+/* Decode parameters == arguments of t3_inference() (R/t3.R:461-463) plus the fields of
+ * the config list handed to cpp_t3_decode (R/t3.R:1022-1034). */
+typedef struct t3mi_params {
+    int32_t max_new_tokens;      /* t3_inference default 1000                              */
+    float temperature;           /* 0.8                                                     */
+    float cfg_weight;            /* 0.5 ; > 0 requires 2 rows per utterance (cond, uncond)  */
+    float top_p;                 /* 0.95 ; 0 => deterministic arg-max           */
+    float min_p;                 /* 0.05                                                    */
+    float repetition_penalty;    /* 1.2                                                     */
+    int32_t start_token;         /* start_speech_token 6561 (R/t3.R:19)                     */
+    int32_t stop_token;          /* stop_speech_token 6562 (R/t3.R:20)                      */
+    int32_t sampler;             /* T3MI_SAMPLER_*                                          */
+    int32_t top_k;               /* turbo only (R/t3.R:1579), 0 = off                       */
+    int32_t max_cache_len;       /* 0 = prompt + max_new_tokens (R path, Q13); else cap (cpp: 350) */
+    int32_t mask_stop;           /* 1 = never emit stop_token (fixed-length bench workloads) */
+    uint64_t seed;               /* stream of the build's counter RNG (libtorch's is not reproducible) */
+} t3mi_params;
+
+typedef struct t3mi_info {
+    int32_t variant, n_layers, d_model, n_heads, head_dim, d_ff, vocab, max_pos, wdtype, device;
+    int64_t weight_bytes;        /* bytes streamed per decode step (P * b_w of SURVEY §8d)  */
+} t3mi_info;
+
+/* per-kernel timing of one decode step (HIP events on the library's stream) */
+typedef struct t3mi_kstat {
+    char name[32];
+    int32_t launches;            /* launches of this kernel per decode step                 */
+    float total_us;              /* summed device time of those launches in one step        */
+    double bytes;                /* algorithmic bytes those launches move                   */
+} t3mi_kstat;
+
+/* Fill `p` with the defaults of t3_inference (R/t3.R:461-463), sampler = T3MI_SAMPLER_R. */
+void t3mi_default_params(t3mi_params* p);
+
+/* Text of the last error on this thread (never NULL). */
+const char* t3mi_last_error(void);
+
+/* Number of visible HIP devices (0 on a box without a GPU; never fails). */
+int t3mi_device_count(void);
+
+/* Open a model from the reference's safetensors layout (keys of R/t3.R:1065-1097,
+ * R/llama.R:566-607; turbo keys R/t3.R:1508-1549), upload to `device`, build RoPE tables
+ * (R/llama.R:87-152).  Replaces load_t3_weights + .get_cpp_weights (R/t3.R:884-912). */
+int t3mi_open(const char* safetensors_path, int variant, int device, int wdtype, t3mi_model** out);
+int t3mi_close(t3mi_model* m);
+int t3mi_get_info(const t3mi_model* m, t3mi_info* info);
+
+/* One utterance, whole loop: prefill + decode until stop_token / max_new_tokens / cache full.
+ * == t3_inference (R/t3.R:461-605) after prepare_input_embeds, and == t3_inference_cpp's
+ * prefill + .Call("cpp_t3_decode") (R/t3.R:987-1036).
+ *   embeds : host float32 [rows, s0, d_model], row-major (rows = 2 with CFG: cond, uncond)
+ *   out    : receives 0-indexed token ids INCLUDING the stop token if hit (Q14); cap >= max_new_tokens
+ * Returns T3MI_OK, T3MI_WARN_CACHE_FULL, or an error. */
+int t3mi_generate(t3mi_model* m, const float* embeds, int rows, int s0, const t3mi_params* p,
+                  int32_t* out, int32_t cap, int32_t* n_out);
+
+/* Many independent utterances decoded together (no reference counterpart
+ * beyond the serial loop of tts_chunked, R/tts.R:462-474).  embeds[u] is [rows_per_utt, s0[u], d];
+ * out is [n_utt, cap]; n_out[u] tokens valid per utterance. */
+int t3mi_generate_batch(t3mi_model* m, int n_utt, int rows_per_utt, const float* const* embeds,
+                        const int32_t* s0, const t3mi_params* p, int32_t* out, int32_t cap,
+                        int32_t* n_out);
+
+/* ---- session API: the same loop in pieces (bench timing, parity hooks) ---------------- */
+
+/* Allocate KV slabs (create_kv_cache, R/llama_traced.R:274-297), upload prompts, run the
+ * prefill (R/t3.R:505 / :987-992) and leave the first logits pending.  `embeds_on_device`
+ * != 0 means every embeds[u] is already a device pointer (inputs resident in HBM). */
+int t3mi_session_begin(t3mi_model* m, int n_utt, int rows_per_utt, const float* const* embeds,
+                       const int32_t* s0, const t3mi_params* p, int embeds_on_device);
+/* Teacher forcing (parity hook): utterance u emits forced[u*n_forced + i] at step i instead of
+ * its own sample.  Call between session_begin and the first session_decode. */
+int t3mi_session_force(t3mi_model* m, const int32_t* forced, int n_forced);
+/* Enqueue `n_steps` decode steps (one token per live utterance per step) on the model's
+ * stream; returns without waiting. */
+int t3mi_session_decode(t3mi_model* m, int n_steps);
+/* Same, bracketed by HIP events on that stream; waits and returns elapsed milliseconds. */
+int t3mi_session_decode_timed(t3mi_model* m, int n_steps, float* ms);
+int t3mi_session_sync(t3mi_model* m);
+/* n_tokens[u], done[u] (1 = hit stop / max_new_tokens / cache full) after a sync. */
+int t3mi_session_status(t3mi_model* m, int32_t* n_tokens, int32_t* done);
+int t3mi_session_tokens(t3mi_model* m, int utt, int32_t* out, int32_t cap, int32_t* n_out);
+/* Raw speech-head logits [rows_total, vocab] of the most recent step (parity hook). */
+int t3mi_session_logits(t3mi_model* m, float* out);
+/* Final filtered distribution of utterance `utt` at the most recent step: ids in descending
+ * probability, their renormalised probabilities; *n = support size (parity hook). */
+int t3mi_session_dist(t3mi_model* m, int utt, int32_t* ids, float* probs, int32_t cap, int32_t* n);
+/* Time every kernel of ONE decode step with HIP events (advances the session by one step). */
+int t3mi_session_profile_step(t3mi_model* m, t3mi_kstat* stats, int cap, int* n_stats);
+int t3mi_session_end(t3mi_model* m);
+
+/* Raw HIP stream of the handle (hipStream_t as void*), for callers that time with their own events. */
+void* t3mi_stream(t3mi_model* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T3MI_H */

@@ -335,15 +335,16 @@ def sampling_tail(logits_cfg: np.ndarray, seen0: Sequence[int], p: SampleParams,
         mask[0] = False                                         # R/t3.R:559 (drops crossing token, Q4)
     else:
         mask = np.concatenate([[False], mask[:-1]])            # src/t3_decode.cpp:352-355
-    sp = np.where(mask, F32(0), sp).astype(F32)
-    sp = (sp / sp.sum(dtype=F32)).astype(F32)
-    nz = int(np.count_nonzero(sp))
+    kept = np.where(mask, F32(0), sp).astype(F32)
+    nz = int(np.count_nonzero(kept))
     # the kept set is a prefix of the sorted order in both variants
-    sup_idx, sup_p = order[:nz].copy(), sp[:nz].copy()
-    # inverse-CDF draw on the final distribution (build's RNG, see counter_uniform)
-    cdf = np.cumsum(sup_p.astype(np.float64))
-    target = u * float(cdf[-1])
-    j = int(np.searchsorted(cdf, target, side="right"))
+    sup_idx = order[:nz].copy()
+    sup_p = (kept[:nz] / kept.sum(dtype=F32)).astype(F32)       # R/t3.R:563
+    # Draw.  libtorch's multinomial stream cannot be reproduced, so the build
+    # defines its own: inverse CDF over the kept prefix of `cum` (the float32 cumsum above)
+    # at target = u * cum[nz-1]; first index whose cumulative mass exceeds the target.
+    target = F32(F32(u) * cum[nz - 1])
+    j = int(np.count_nonzero(cum[:nz] <= target))
     j = min(j, nz - 1)
     return TailResult(int(sup_idx[j]), sup_idx, sup_p, lg)
 

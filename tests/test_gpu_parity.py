@@ -1,0 +1,130 @@
+"""GPU parity: the HIP path through the C ABI vs the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): fp32 logits within 1e-3 relative (max|a-b|/max|b|),
+identical greedy token sequences; sampled runs compare the filtered distribution (support
+set + probabilities) and, because both sides use the same counter RNG, the drawn tokens."""
+import os
+
+import numpy as np
+import pytest
+
+import chatterbox_amd as cb
+from chatterbox_amd import _lib, synth
+from oracle import t3_oracle as O
+from tests.helpers import oracle_model, rel_err
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3     # fp32, relative to max |logit|
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    dims = synth.TINY
+    path = synth.ensure_checkpoint(dims, 1234)
+    model = cb.load_t3(path, device=0, start_speech_token=dims.start_speech_token,
+                       stop_speech_token=dims.stop_speech_token)
+    yield dims, model, oracle_model(dims, 1234)
+    model.close()
+
+
+def test_tiny_teacher_forced_logits_and_distributions(tiny):
+    dims, model, om = tiny
+    emb = synth.synth_embeds(2, 17, dims.hidden_size, 21)
+    n = 24
+    p = O.SampleParams(max_new_tokens=n, seed=5)                     # t3_inference defaults
+    ref = O.t3_inference(om, emb, p, mask_stop=True)
+    with cb.Session(model, [emb], max_new_tokens=n, seed=5, mask_stop=True, forced=np.array(ref.tokens)) as s:
+        for i in range(n):
+            assert rel_err(s.logits(), ref.raw_logits[i]) < LOGIT_TOL, f"step {i}"
+            s.decode(1)
+            ids, pr = s.dist(0)
+            t = ref.tails[i]
+            assert list(ids) == list(t.sorted_idx), f"support differs at step {i}"
+            np.testing.assert_allclose(pr, t.sorted_probs, rtol=1e-3, atol=1e-6)
+        assert list(s.tokens(0)) == ref.tokens
+
+
+@pytest.mark.parametrize("variant,sampler", [("r", _lib.SAMPLER_R), ("cpp", _lib.SAMPLER_CPP)])
+def test_tiny_sampled_tokens_match_oracle_rng(tiny, variant, sampler):
+    dims, model, om = tiny
+    emb = synth.synth_embeds(2, 9, dims.hidden_size, 33)
+    n = 40
+    cache = 350 if variant == "cpp" else 0
+    p = O.SampleParams(max_new_tokens=n, seed=11, variant=variant, top_p=0.9, min_p=0.02, max_cache_len=cache)
+    ref = O.t3_inference(om, emb, p)
+    with cb.Session(model, [emb], max_new_tokens=n, seed=11, top_p=0.9, min_p=0.02, sampler=sampler,
+                    max_cache_len=cache) as s:
+        s.decode(n)
+        toks = s.tokens(0)
+    assert list(toks) == ref.tokens
+
+
+def test_tiny_greedy_generate_matches_oracle(tiny):
+    dims, model, om = tiny
+    emb = synth.synth_embeds(2, 30, dims.hidden_size, 44)
+    n = 64
+    ref = O.t3_inference(om, emb, O.SampleParams(max_new_tokens=n, top_p=0.0), keep_logits=False)
+    toks = cb.t3_inference(model, emb, max_new_tokens=n, top_p=0.0)
+    assert list(toks) == ref.tokens
+
+
+def test_tiny_no_cfg_single_row(tiny):
+    dims, model, om = tiny
+    emb = synth.synth_embeds(1, 11, dims.hidden_size, 55)
+    n = 16
+    ref = O.t3_inference(om, emb, O.SampleParams(max_new_tokens=n, top_p=0.0, cfg_weight=0.0), keep_logits=False)
+    toks = cb.t3_inference(model, emb, max_new_tokens=n, top_p=0.0, cfg_weight=0.0)
+    assert list(toks) == ref.tokens
+
+
+def test_tiny_ragged_batch_matches_per_utterance_oracle(tiny):
+    dims, model, om = tiny
+    lens = [5, 19, 12]
+    embs = [synth.synth_embeds(2, L, dims.hidden_size, 100 + i) for i, L in enumerate(lens)]
+    n = 12
+    outs = cb.t3_inference_batch(model, embs, max_new_tokens=n, top_p=0.0, mask_stop=True)
+    for e, got in zip(embs, outs):
+        ref = O.t3_inference(om, e, O.SampleParams(max_new_tokens=n, top_p=0.0), keep_logits=False, mask_stop=True)
+        assert list(got) == ref.tokens
+
+
+def test_tiny_stop_token_ends_generation_and_is_returned(tiny):
+    """Q14: the R path returns the stop token; the cpp wrapper strips it (R/t3.R:1039-1045)."""
+    dims, model, om = tiny
+    emb = synth.synth_embeds(2, 8, dims.hidden_size, 66)
+    forced = np.array([3, 4, dims.stop_speech_token, 7, 8])
+    with cb.Session(model, [emb], max_new_tokens=5, top_p=0.0, forced=forced) as s:
+        s.decode(5)
+        ntok, done = s.status()
+        assert ntok[0] == 3 and done[0] == 1
+        assert list(s.tokens(0)) == [3, 4, dims.stop_speech_token]
+
+
+def test_error_paths(tiny):
+    dims, model, om = tiny
+    emb = synth.synth_embeds(1, 4, dims.hidden_size, 1)
+    with pytest.raises(ValueError):
+        cb.t3_inference(model, emb, cfg_weight=0.5)           # CFG needs two rows
+    with pytest.raises(_lib.T3miError) as ei:
+        cb.t3_inference_cpp(model, synth.synth_embeds(2, 400, dims.hidden_size, 2))
+    assert ei.value.code == _lib.ERR_ARG                        # prompt longer than the 350-slot cache
+
+
+def test_full_size_model_logits_and_greedy_tokens():
+    """Llama-520M shapes (30 x d1024/F4096, V 8194), synthetic weights in the reference layout."""
+    dims = synth.FULL
+    path = synth.ensure_checkpoint(dims, 1234)
+    om = oracle_model(dims, 1234)
+    emb = synth.synth_embeds(2, 6, dims.hidden_size, 77)
+    n = 5
+    ref = O.t3_inference(om, emb, O.SampleParams(max_new_tokens=n, top_p=0.0), mask_stop=True)
+    model = cb.load_t3(path, device=0)
+    try:
+        with cb.Session(model, [emb], max_new_tokens=n, top_p=0.0, mask_stop=True) as s:
+            for i in range(n):
+                assert rel_err(s.logits(), ref.raw_logits[i]) < LOGIT_TOL, f"step {i}"
+                s.decode(1)
+            assert list(s.tokens(0)) == ref.tokens
+    finally:
+        model.close()
