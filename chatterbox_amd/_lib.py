@@ -70,6 +70,7 @@ SYMBOLS = {
     "t3mi_session_tokens": (C.c_int, [_H, C.c_int, _IP, C.c_int32, _IP]),
     "t3mi_session_logits": (C.c_int, [_H, _FP]),
     "t3mi_session_dist": (C.c_int, [_H, C.c_int, _IP, _FP, C.c_int32, _IP]),
+    "t3mi_session_drawn": (C.c_int, [_H, _IP]),
     "t3mi_session_profile_step": (C.c_int, [_H, C.POINTER(KStat), C.c_int, C.POINTER(C.c_int)]),
     "t3mi_session_end": (C.c_int, [_H]),
     "t3mi_stream": (C.c_void_p, [_H]),

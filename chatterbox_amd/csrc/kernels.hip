@@ -51,46 +51,58 @@ struct BF16W {
     }
 };
 
-// ---- GEMV: y[r][n] = sum_k W[n][k] * xn[r][k], 4 output rows per wave-chunk ------------------
+// ---- GEMV: y[r][n] = sum_k W[n][k] * xs[r][k] ---------------------------------------------------
 //
-// A wave owns a "chunk" of 4 output features and the whole K (KSPLIT==1) or one quarter of K
-// (KSPLIT==4, the 4 waves of the block then combine through LDS in a fixed order).  Lane l holds
-// k = c*64*E + l*E .. +E-1 of every row, so one wave-instruction reads 1 KiB contiguous.
-// Which 4 features form a chunk depends on the epilogue:
-//   STORE/RESID : n = 4c .. 4c+3
-//   ROPE_KV     : matrix hm = c/16 (q heads, k heads, v heads), i0 = 2*(c%16):
-//                 n = hm*64 + {i0, i0+1, i0+32, i0+33}   -> both halves of a rotate_half pair
-//   SWIGLU      : gate rows {2c, 2c+1} and up rows {F+2c, F+2c+1} (F = N/2)
-template <int EPI>
+// Block = NW waves.  The block first issues the weight loads of its first chunk (longest latency
+// first), then builds the activation rows xs[R][K] ONCE in LDS through one of three prologues:
+//   PRO_PLAIN : copy x                                   (down_proj: x = SwiGLU output)
+//   PRO_NORM  : RMSNorm, w * (x * rsqrt(mean(x^2)+eps))  (R/llama.R:65-72)
+//   PRO_ATTN  : combine the split-softmax partials of the decode attention kernel
+// A wave owns a chunk of ROWS output features over the whole K (KSPLIT == 1) or one quarter of K
+// (KSPLIT == 4: the 4 waves of a group combine through LDS in a fixed order).  Lane l holds
+// k = q*64*E + l*E .. +E-1 of every row, so one wave-instruction reads 1 KiB contiguous.
+// Which features form a chunk depends on the epilogue:
+//   STORE/RESID : n = ROWS*c + j
+//   ROPE_KV     : both halves (i, i+32) of rotate_half pairs of one head of q, k or v
+//   SWIGLU      : gate rows and the matching up rows (F = N/2 apart)
+template <int EPI, int ROWS>
 __device__ __forceinline__ int chunk_row(int c, int j, int N) {
+    constexpr int HP = ROWS / 2;  // pairs per chunk (ROPE / SWIGLU)
     if (EPI == EPI_ROPE_KV) {
-        const int hm = c >> 4, i0 = (c & 15) << 1;
-        return hm * kHeadDim + i0 + (j & 1) + ((j >> 1) << 5);
+        const int per_head = 32 / HP;                 // chunks per 64-row head matrix
+        const int hm = c / per_head, i0 = (c % per_head) * HP;
+        return hm * kHeadDim + i0 + (j % HP) + (j / HP) * 32;
     } else if (EPI == EPI_SWIGLU) {
-        return (j >> 1) * (N >> 1) + 2 * c + (j & 1);
+        return (j / HP) * (N >> 1) + HP * c + (j % HP);
     } else {
-        return 4 * c + j;
+        return ROWS * c + j;
     }
 }
 
-template <typename WT, int R, int NK, int KSPLIT, int EPI, bool NORM>
-__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a, int n_chunks) {
+template <typename WT, int R, int NK, int KSPLIT, int ROWS, int EPI, int PRO>
+__global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
     constexpr int E = WT::E;
     constexpr int KW = NK * kWave * E;  // K elements handled by one wave
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int K = KW * KSPLIT;
-    const int kbase = (KSPLIT > 1) ? wave * KW : 0;
+    constexpr int K = KW * KSPLIT;
+    static_assert(EPI == EPI_STORE || EPI == EPI_RESID || (ROWS % 2 == 0), "paired epilogues need even ROWS");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                       // [R][K]
+    float* part = smem + R * K;             // [NW][ROWS][R] (KSPLIT > 1) / reduction scratch
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    const int grp = wave / KSPLIT, kpart = wave % KSPLIT, ngrp = nw / KSPLIT;
+    const int kbase = kpart * KW;
 
-    int c = (KSPLIT > 1) ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
-    const int cstride = (KSPLIT > 1) ? (int)gridDim.x : (int)gridDim.x * 4;
+    // block-uniform trip count: every wave runs the same number of iterations (barriers inside)
+    int cb = (int)blockIdx.x * ngrp;
+    const int cstride = (int)gridDim.x * ngrp;
+    int c = cb + grp;
 
-    // ---- issue the first chunk's weight loads before touching x (longest latency first)
-    float w[4][NK][E];
+    float w[ROWS][NK][E];
     auto load_chunk = [&](int cc) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int row = chunk_row<EPI>(cc, j, a.N);
+        for (int j = 0; j < ROWS; ++j) {
+            int row = chunk_row<EPI, ROWS>(cc, j, a.N);
             row = row < a.N ? row : a.N - 1;
             const size_t off = (size_t)row * K + kbase + lane * E;
 #pragma unroll
@@ -99,7 +111,67 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a, int n_chunks) {
     };
     if (c < n_chunks) load_chunk(c);
 
-    // ---- activation rows for this lane's k-slice (+ fused RMSNorm, R/llama.R:65-72)
+    // ---- prologue: activation rows -> LDS
+    if (PRO == PRO_PLAIN) {
+        for (int i = tid * 4; i < R * K; i += nthr * 4)
+            *reinterpret_cast<float4*>(xs + i) = *reinterpret_cast<const float4*>(a.x + i);
+    } else if (PRO == PRO_NORM) {
+        float ss[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float t = 0.f;
+            for (int i = tid * 4; i < K; i += nthr * 4) {
+                const float4 v = *reinterpret_cast<const float4*>(a.x + (size_t)r * K + i);
+                t = fmaf(v.x, v.x, t); t = fmaf(v.y, v.y, t); t = fmaf(v.z, v.z, t); t = fmaf(v.w, v.w, t);
+            }
+            ss[r] = wave_sum(t);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) part[wave * R + r] = ss[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float t = 0.f;
+            for (int ww = 0; ww < nw; ++ww) t += part[ww * R + r];
+            const float rs = 1.0f / sqrtf(t / (float)K + a.eps);
+            for (int i = tid * 4; i < K; i += nthr * 4) {
+                const float4 v = *reinterpret_cast<const float4*>(a.x + (size_t)r * K + i);
+                const float4 g = *reinterpret_cast<const float4*>(a.ln_w + i);
+                float4 o;
+                o.x = __fmul_rn(g.x, __fmul_rn(v.x, rs)); o.y = __fmul_rn(g.y, __fmul_rn(v.y, rs));
+                o.z = __fmul_rn(g.z, __fmul_rn(v.z, rs)); o.w = __fmul_rn(g.w, __fmul_rn(v.w, rs));
+                *reinterpret_cast<float4*>(xs + r * K + i) = o;
+            }
+        }
+    } else {  // PRO_ATTN: softmax-merge the per-split partials (attn_split_kernel)
+        const int H = K / kHeadDim;
+        for (int idx = tid; idx < R * (K / 4); idx += nthr) {
+            const int r = idx / (K / 4), k4 = idx % (K / 4);
+            const int head = k4 >> 4, dd = (k4 & 15) << 2;
+            const int pos = a.rowpos[r];
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pos >= 0) {
+                const int ns = pos / a.keys_per_split + 1;
+                const size_t b = ((size_t)r * H + head) * a.n_split_max;
+                float M = -INFINITY;
+                for (int s = 0; s < ns; ++s) M = fmaxf(M, a.pm[b + s]);
+                float den = 0.f;
+                for (int s = 0; s < ns; ++s) {
+                    const float ws = expf(a.pm[b + s] - M);
+                    den = fmaf(ws, a.pl[b + s], den);
+                    const float4 v = *reinterpret_cast<const float4*>(a.pacc + (b + s) * kHeadDim + dd);
+                    o.x = fmaf(ws, v.x, o.x); o.y = fmaf(ws, v.y, o.y);
+                    o.z = fmaf(ws, v.z, o.z); o.w = fmaf(ws, v.w, o.w);
+                }
+                o.x /= den; o.y /= den; o.z /= den; o.w /= den;
+            }
+            *reinterpret_cast<float4*>(xs + r * K + k4 * 4) = o;
+        }
+    }
+    __syncthreads();
+
     float xv[R][NK][E];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -107,41 +179,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a, int n_chunks) {
         for (int q = 0; q < NK; ++q)
 #pragma unroll
             for (int e4 = 0; e4 < E; e4 += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(a.x + (size_t)r * K + kbase + q * kWave * E + lane * E + e4);
+                const float4 v = *reinterpret_cast<const float4*>(xs + r * K + kbase + q * kWave * E + lane * E + e4);
                 xv[r][q][e4 + 0] = v.x; xv[r][q][e4 + 1] = v.y; xv[r][q][e4 + 2] = v.z; xv[r][q][e4 + 3] = v.w;
             }
-    if (NORM) {
-        static_assert(!NORM || KSPLIT == 1, "norm prologue needs the whole row in one wave");
-        float lw[NK][E];
-#pragma unroll
-        for (int q = 0; q < NK; ++q)
-#pragma unroll
-            for (int e4 = 0; e4 < E; e4 += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(a.ln_w + q * kWave * E + lane * E + e4);
-                lw[q][e4 + 0] = v.x; lw[q][e4 + 1] = v.y; lw[q][e4 + 2] = v.z; lw[q][e4 + 3] = v.w;
-            }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float ss = 0.f;
-#pragma unroll
-            for (int q = 0; q < NK; ++q)
-#pragma unroll
-                for (int e = 0; e < E; ++e) ss = fmaf(xv[r][q][e], xv[r][q][e], ss);
-            ss = wave_sum(ss);
-            const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
-#pragma unroll
-            for (int q = 0; q < NK; ++q)
-#pragma unroll
-                for (int e = 0; e < E; ++e) xv[r][q][e] = __fmul_rn(lw[q][e], __fmul_rn(xv[r][q][e], rs));
-        }
-    }
 
-    __shared__ float part[4][4][R];
-
-    for (; c < n_chunks; c += cstride) {
-        float acc[4][R];
+    for (; cb < n_chunks; cb += cstride, c += cstride) {
+        const bool live = c < n_chunks;
+        float acc[ROWS][R];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < ROWS; ++j)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float s = 0.f;
@@ -154,37 +200,40 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a, int n_chunks) {
         const int cn = c + cstride;
         if (cn < n_chunks) load_chunk(cn);  // next chunk's loads fly during the reduction
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < ROWS; ++j)
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[j][r] = wave_sum(acc[j][r]);
 
         if (KSPLIT > 1) {
+            __syncthreads();  // previous iteration's readers are done with part[]
             if (lane == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < ROWS; ++j)
 #pragma unroll
-                    for (int r = 0; r < R; ++r) part[wave][j][r] = acc[j][r];
+                    for (int r = 0; r < R; ++r) part[(wave * ROWS + j) * R + r] = acc[j][r];
             }
             __syncthreads();
-            if (threadIdx.x < 4 * R) {
-                const int j = threadIdx.x / R, r = threadIdx.x % R;
-                float s = part[0][j][r];
+            // every wave of the group re-reads the K-partials in a fixed order
 #pragma unroll
-                for (int ww = 1; ww < KSPLIT; ++ww) s += part[ww][j][r];
-                const int n = chunk_row<EPI>(c, j, a.N);
-                if (n < a.N) {
-                    const size_t o = (size_t)r * a.ldy + n;
-                    a.y[o] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o], s) : s;
+            for (int j = 0; j < ROWS; ++j)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float s = part[((grp * KSPLIT) * ROWS + j) * R + r];
+#pragma unroll
+                    for (int ww = 1; ww < KSPLIT; ++ww) s += part[((grp * KSPLIT + ww) * ROWS + j) * R + r];
+                    acc[j][r] = s;
                 }
-            }
-            __syncthreads();
-        } else if (EPI == EPI_STORE || EPI == EPI_RESID) {
+            if (kpart != 0) continue;  // one wave of the group writes
+        }
+        if (!live) continue;
+
+        if (EPI == EPI_STORE || EPI == EPI_RESID) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < ROWS; ++j)
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     if (lane == j * R + r) {
-                        const int n = 4 * c + j;
+                        const int n = ROWS * c + j;
                         if (n < a.N) {
                             const size_t o = (size_t)r * a.ldy + n;
                             a.y[o] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o], acc[j][r]) : acc[j][r];
@@ -192,28 +241,31 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a, int n_chunks) {
                     }
         } else if (EPI == EPI_SWIGLU) {
             // silu(g) * u with silu(g) = g * sigmoid(g)  (R/llama.R:302, 307)
+            constexpr int HP = ROWS / 2;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < HP; ++j)
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     if (lane == j * R + r) {
-                        const float g = acc[j][r], u = acc[j + 2][r];
+                        const float g = acc[j][r], u = acc[j + HP][r];
                         const float sg = 1.0f / (1.0f + expf(-g));
-                        a.y[(size_t)r * a.ldy + 2 * c + j] = __fmul_rn(__fmul_rn(g, sg), u);
+                        a.y[(size_t)r * a.ldy + HP * c + j] = __fmul_rn(__fmul_rn(g, sg), u);
                     }
         } else {  // EPI_ROPE_KV
+            constexpr int HP = ROWS / 2;
             const int H = a.n_heads;
-            const int hm = c >> 4, i0 = (c & 15) << 1;
+            const int per_head = 32 / HP;
+            const int hm = c / per_head, i0 = (c % per_head) * HP;
             const int kind = hm / H, head = hm % H;  // 0 q, 1 k, 2 v
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+            for (int jj = 0; jj < HP; ++jj)
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     if (lane == jj * R + r) {
                         const int pos = a.rowpos[r];
                         if (pos >= 0) {
                             const int i = i0 + jj;
-                            float lo = acc[jj][r], hi = acc[jj + 2][r];
+                            float lo = acc[jj][r], hi = acc[jj + HP][r];
                             if (kind < 2) {
                                 // q*cos + rotate_half(q)*sin, each product rounded (R/llama.R:184-185)
                                 const float cl = a.rope_cos[(size_t)pos * kHeadDim + i];
@@ -238,75 +290,85 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a, int n_chunks) {
     }
 }
 
-// ---- single-query attention over the KV cache (R/llama.R:257-264, src/t3_decode.cpp:151-160) --
-// grid (H, rows); block 256 = 16 groups of 16 lanes; a group owns one key at a time, each lane 4 dims.
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
-    extern __shared__ float smem[];
-    const int h = blockIdx.x, r = blockIdx.y;
+// ---- single-query attention over the KV cache, split along the keys ---------------------------------
+// (R/llama.R:257-264, src/t3_decode.cpp:151-160.)  grid (H, rows, n_split_max); block 256 = 16 groups
+// of 16 lanes; a group owns one key at a time, each lane 4 of its 64 dims.  Block (h, r, s) covers keys
+// [s*kps, (s+1)*kps) of row r / head h and writes an UNNORMALISED partial (m, l, acc[64]); the o_proj
+// kernel's PRO_ATTN prologue merges the partials, so no atomics and no inter-block hand-off are needed.
+// All K and V loads of a 64-key pass are issued before the first use (one HBM round trip per pass).
+__global__ __launch_bounds__(256) void attn_split_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[16 * kHeadDim + 32];
+    const int h = blockIdx.x, r = blockIdx.y, sp = blockIdx.z;
     const int pos = a.rowpos[r];
     if (pos < 0) return;
     const int L = pos + 1;
-    const int tid = threadIdx.x, g = tid >> 4, sub = tid & 15;
+    const int k0 = sp * a.keys_per_split;
+    if (k0 >= L) return;
+    const int k1 = min(L, k0 + a.keys_per_split);
+    const int tid = threadIdx.x, g = tid >> 4, sub = tid & 15, wave = tid >> 6;
     const int d = a.n_heads * kHeadDim;
-    float* sc = smem;                 // [max_len]
-    float* red = smem + a.max_len;    // [16][64] + 8
     const size_t base = ((size_t)r * a.n_heads + h) * a.max_len * kHeadDim;
     const float* Kp = a.kcache + base;
     const float* Vp = a.vcache + base;
     const float4 q4 = *reinterpret_cast<const float4*>(a.q + (size_t)r * d + h * kHeadDim + sub * 4);
 
-    for (int j0 = g; j0 < L; j0 += 64) {
-        float dot[4];
+    float m_run = -INFINITY, l_run = 0.f;           // l_run: this group's share
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);   // this group's share, dims sub*4..+3
+    for (int p0 = k0; p0 < k1; p0 += 64) {
+        float4 kv[4], vv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int j = j0 + 16 * u;
-            const int jc = j < L ? j : L - 1;
-            const float4 k4 = *reinterpret_cast<const float4*>(Kp + (size_t)jc * kHeadDim + sub * 4);
-            dot[u] = fmaf(q4.w, k4.w, fmaf(q4.z, k4.z, fmaf(q4.y, k4.y, q4.x * k4.x)));
+            const int j = p0 + g + 16 * u;
+            const int jc = j < k1 ? j : k1 - 1;
+            kv[u] = *reinterpret_cast<const float4*>(Kp + (size_t)jc * kHeadDim + sub * 4);
+            vv[u] = *reinterpret_cast<const float4*>(Vp + (size_t)jc * kHeadDim + sub * 4);
         }
+        float sc[4];
+        float mloc = -INFINITY;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            float dot = fmaf(q4.w, kv[u].w, fmaf(q4.z, kv[u].z, fmaf(q4.y, kv[u].y, q4.x * kv[u].x)));
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) dot[u] += __shfl_xor(dot[u], o, 16);
-            const int j = j0 + 16 * u;
-            if (sub == 0 && j < L) sc[j] = dot[u] * 0.125f;  // 1/sqrt(64)
+            for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 16);
+            sc[u] = (p0 + g + 16 * u < k1) ? dot * 0.125f : -INFINITY;  // 1/sqrt(64)
+            mloc = fmaxf(mloc, sc[u]);
         }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, kWave));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, kWave));
+        __syncthreads();
+        if ((tid & 63) == 0) red[16 * kHeadDim + wave] = mloc;
+        __syncthreads();
+        const float mp = fmaxf(fmaxf(red[16 * kHeadDim], red[16 * kHeadDim + 1]),
+                               fmaxf(red[16 * kHeadDim + 2], red[16 * kHeadDim + 3]));
+        const float m_new = fmaxf(m_run, mp);
+        const float scale = expf(m_run - m_new);  // 0 on the first pass (m_run = -inf)
+        acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+        l_run *= scale;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float e = expf(sc[u] - m_new);  // exp(-inf) = 0 for padded keys
+            l_run += e;
+            acc.x = fmaf(e, vv[u].x, acc.x); acc.y = fmaf(e, vv[u].y, acc.y);
+            acc.z = fmaf(e, vv[u].z, acc.z); acc.w = fmaf(e, vv[u].w, acc.w);
+        }
+        m_run = m_new;
     }
     __syncthreads();
-    // softmax over sc[0..L)
-    float m = -INFINITY;
-    for (int j = tid; j < L; j += 256) m = fmaxf(m, sc[j]);
-    m = wave_max(m);
-    if ((tid & 63) == 0) red[tid >> 6] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float s = 0.f;
-    for (int j = tid; j < L; j += 256) {
-        const float e = expf(sc[j] - m);
-        sc[j] = e;
-        s += e;
-    }
-    s = wave_sum(s);
-    if ((tid & 63) == 0) red[tid >> 6] = s;
-    __syncthreads();
-    s = (red[0] + red[1]) + (red[2] + red[3]);
-    __syncthreads();
-    // out = (e / s) @ V
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = g; j < L; j += 16) {
-        const float p = sc[j] / s;
-        const float4 v4 = *reinterpret_cast<const float4*>(Vp + (size_t)j * kHeadDim + sub * 4);
-        acc.x = fmaf(p, v4.x, acc.x); acc.y = fmaf(p, v4.y, acc.y);
-        acc.z = fmaf(p, v4.z, acc.z); acc.w = fmaf(p, v4.w, acc.w);
-    }
     *reinterpret_cast<float4*>(red + g * kHeadDim + sub * 4) = acc;
+    if (sub == 0) red[16 * kHeadDim + 8 + g] = l_run;
     __syncthreads();
+    const size_t pb = ((size_t)r * a.n_heads + h) * a.n_split_max + sp;
     if (tid < kHeadDim) {
         float o = 0.f;
 #pragma unroll
         for (int gg = 0; gg < 16; ++gg) o += red[gg * kHeadDim + tid];
-        a.out[(size_t)r * d + h * kHeadDim + tid] = o;
+        a.pacc[pb * kHeadDim + tid] = o;
+    } else if (tid == 64) {
+        float l = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) l += red[16 * kHeadDim + 8 + gg];
+        a.pl[pb] = l;
+        a.pm[pb] = m_run;
     }
 }
 
@@ -401,6 +463,7 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
 
     // 1. CFG, penalty, temperature  (R/t3.R:518-537)
     float lmax = -INFINITY;
+#pragma unroll 4
     for (int v = tid; v < V; v += kSampThreads) {
         float l = lc[v];
         if (use_cfg) l = __fadd_rn(l, __fmul_rn(a.cfg_w, __fsub_rn(l, lc[V + v])));
@@ -439,6 +502,39 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
         s2 += p;
     }
     s2 = block_reduce_sum(s2, scratch);
+    int tok;
+    int kkeep;
+    float s3;
+    if (a.top_p <= 0.f) {
+        // top_p = 0: cumsum > 0 everywhere, only sorted index 0 survives in both variants (Q6), i.e. the
+        // arg-max of the filtered distribution with ties to the lowest id -- no sort needed.
+        unsigned long long best = 0ull;
+        for (int v = tid; v < V; v += kSampThreads) {
+            const float p = __fdiv_rn(lg[v], s2);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(p) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)v);
+            if (p > 0.f && key > best) best = key;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long t = __shfl_xor(best, o, kWave);
+            best = t > best ? t : best;
+        }
+        unsigned long long* sk = reinterpret_cast<unsigned long long*>(tot);
+        __syncthreads();
+        if ((tid & 63) == 0) sk[tid >> 6] = best;
+        __syncthreads();
+        best = sk[0];
+#pragma unroll
+        for (int i = 1; i < kSampThreads / 64; ++i) best = sk[i] > best ? sk[i] : best;
+        kkeep = best ? 1 : 0;
+        tok = best ? (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull)) : -1;
+        s3 = __uint_as_float((unsigned)(best >> 32));
+        if (tid == 0) {
+            kp[0] = (unsigned)(best >> 32);
+            ki[0] = (uint16_t)(tok < 0 ? 0xFFFF : tok);
+        }
+        __syncthreads();
+    } else {
     // 4. compact the non-zero entries into (prob bits, id) keys
     if (tid == 0) misc[0] = 0;
     __syncthreads();
@@ -531,13 +627,13 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
         if (cnt) atomicAdd(&misc[1], cnt);
     }
     __syncthreads();
-    const int kkeep = misc[1];
-    float s3 = 0.f;
+    kkeep = misc[1];
+    s3 = 0.f;
     for (int i = tid; i < kkeep; i += kSampThreads) s3 += __uint_as_float(kp[i]);
     s3 = block_reduce_sum(s3, scratch);
     // 8. draw: inverse CDF over the kept prefix with the build's counter RNG
     const float uu = counter_uniform(a.seed, (unsigned long long)u, (unsigned long long)step);
-    const float target = __fmul_rn(uu, cum[kkeep - 1]);
+    const float target = __fmul_rn(uu, kkeep > 0 ? cum[kkeep - 1] : 0.f);
     if (tid == 0) misc[2] = 0;
     __syncthreads();
     {
@@ -548,8 +644,11 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
     __syncthreads();
     int jsel = misc[2];
     if (jsel > kkeep - 1) jsel = kkeep - 1;
-    int tok = (int)ki[jsel];
+    tok = (kkeep > 0) ? (int)ki[jsel < 0 ? 0 : jsel] : -1;
+    }  // general (sorted) path
+    if (a.drawn != nullptr && tid == 0) a.drawn[u] = tok;
     if (a.forced != nullptr && step < a.n_forced) tok = a.forced[(size_t)u * a.n_forced + step];
+    if (tok < 0 || tok >= V) tok = a.stop_token;  // degenerate logits (all NaN): end the utterance
 
     if (a.dist_ids != nullptr) {
         const int m = kkeep < a.dist_cap ? kkeep : a.dist_cap;
@@ -582,16 +681,25 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
     }
 }
 
-template <typename WT, int R, int NK, int KSPLIT, int EPI, bool NORM>
+template <typename WT, int R, int NK, int KSPLIT, int ROWS, int EPI, int PRO>
 hipError_t launch_gemv_t(const GemvArgs& a, hipStream_t s) {
-    int n_chunks;
-    if (EPI == EPI_ROPE_KV) n_chunks = (a.N / kHeadDim) * 16;
-    else if (EPI == EPI_SWIGLU) n_chunks = a.N / 4;
-    else n_chunks = (a.N + 3) / 4;
-    int grid = (KSPLIT > 1) ? n_chunks : (n_chunks + 3) / 4;
-    const int max_grid = 256 * 8;
-    if (grid > max_grid) grid = max_grid;
-    hipLaunchKernelGGL((gemv_kernel<WT, R, NK, KSPLIT, EPI, NORM>), dim3(grid), dim3(256), 0, s, a, n_chunks);
+    constexpr int K = NK * kWave * WT::E * KSPLIT;
+    const int n_chunks = (a.N + ROWS - 1) / ROWS;
+    // waves per block: aim at one block per CU (256 CUs) with every load of the launch in flight at once
+    int nw = a.waves > 0 ? a.waves : 4;
+    if (nw % KSPLIT) nw = ((nw + KSPLIT - 1) / KSPLIT) * KSPLIT;
+    if (nw > 8) nw = 8;
+    const int per_block = nw / KSPLIT;
+    int grid = (n_chunks + per_block - 1) / per_block;
+    if (grid > 256 * 8) grid = 256 * 8;
+    const size_t lds = ((size_t)R * K + (size_t)nw * ROWS * R + 32) * sizeof(float);
+    auto kfn = gemv_kernel<WT, R, NK, KSPLIT, ROWS, EPI, PRO>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(nw * 64), lds, s, a, n_chunks);
     return hipGetLastError();
 }
 
@@ -599,13 +707,15 @@ template <typename WT, int R, int NK>
 hipError_t launch_gemv_rn(const GemvArgs& a, int epi, int ksplit, hipStream_t s) {
     if (ksplit == 1) {
         switch (epi) {
-            case EPI_STORE: return launch_gemv_t<WT, R, NK, 1, EPI_STORE, true>(a, s);
-            case EPI_ROPE_KV: return launch_gemv_t<WT, R, NK, 1, EPI_ROPE_KV, true>(a, s);
-            case EPI_SWIGLU: return launch_gemv_t<WT, R, NK, 1, EPI_SWIGLU, true>(a, s);
-            case EPI_RESID: return launch_gemv_t<WT, R, NK, 1, EPI_RESID, false>(a, s);
+            case EPI_STORE: return launch_gemv_t<WT, R, NK, 1, 4, EPI_STORE, PRO_NORM>(a, s);
+            case EPI_ROPE_KV: return launch_gemv_t<WT, R, NK, 1, 2, EPI_ROPE_KV, PRO_NORM>(a, s);
+            case EPI_SWIGLU: return launch_gemv_t<WT, R, NK, 1, 4, EPI_SWIGLU, PRO_NORM>(a, s);
+            case EPI_RESID:
+                if (a.pacc != nullptr) return launch_gemv_t<WT, R, NK, 1, 1, EPI_RESID, PRO_ATTN>(a, s);
+                return launch_gemv_t<WT, R, NK, 1, 1, EPI_RESID, PRO_PLAIN>(a, s);
         }
-    } else if (ksplit == 4 && epi == EPI_RESID) {
-        return launch_gemv_t<WT, R, NK, 4, EPI_RESID, false>(a, s);
+    } else if (ksplit == 4 && epi == EPI_RESID && a.pacc == nullptr) {
+        return launch_gemv_t<WT, R, NK, 4, 4, EPI_RESID, PRO_PLAIN>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -644,10 +754,19 @@ size_t sampler_lds_bytes(int V) {
 }
 
 hipError_t launch_gemv(const GemvArgs& a, int epilogue, int wdtype, hipStream_t s) {
-    if (a.W == nullptr || a.x == nullptr || a.y == nullptr || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
+    if (a.W == nullptr || a.y == nullptr || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
     const bool norm = (epilogue != EPI_RESID);
-    if (norm && a.ln_w == nullptr) return hipErrorInvalidValue;
-    if (epilogue == EPI_RESID && a.resid == nullptr) return hipErrorInvalidValue;
+    if (norm && (a.ln_w == nullptr || a.x == nullptr)) return hipErrorInvalidValue;
+    if (epilogue == EPI_RESID) {
+        if (a.resid == nullptr) return hipErrorInvalidValue;
+        if (a.pacc != nullptr) {  // attention-merge prologue
+            if (a.pm == nullptr || a.pl == nullptr || a.rowpos == nullptr || a.keys_per_split <= 0 ||
+                a.n_split_max <= 0 || a.K % kHeadDim)
+                return hipErrorInvalidValue;
+        } else if (a.x == nullptr) {
+            return hipErrorInvalidValue;
+        }
+    }
     if (epilogue == EPI_SWIGLU && (a.N % 4)) return hipErrorInvalidValue;
     if (epilogue == EPI_ROPE_KV) {
         if (a.N != 3 * a.n_heads * kHeadDim || a.rowpos == nullptr || a.kcache == nullptr ||
@@ -658,10 +777,11 @@ hipError_t launch_gemv(const GemvArgs& a, int epilogue, int wdtype, hipStream_t 
 }
 
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t s) {
-    if (a.rows <= 0 || a.n_heads <= 0 || a.max_len <= 0) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)a.max_len + 16 * kHeadDim + 8) * sizeof(float);
-    if (lds > 150 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(a.n_heads, a.rows), dim3(256), lds, s, a);
+    if (a.rows <= 0 || a.n_heads <= 0 || a.max_len <= 0 || a.n_split_max <= 0 || a.keys_per_split <= 0 ||
+        (a.keys_per_split % 64) || a.pm == nullptr || a.pl == nullptr || a.pacc == nullptr)
+        return hipErrorInvalidValue;
+    if ((long long)a.n_split_max * a.keys_per_split < a.max_len) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_split_kernel, dim3(a.n_heads, a.rows, a.n_split_max), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

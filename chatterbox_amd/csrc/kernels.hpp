@@ -13,6 +13,12 @@ enum Epilogue : int {
     EPI_SWIGLU = 3,   // y[r][n] = silu(gate_n) * up_n                   (R/llama.R:305-308)
 };
 
+enum Prologue : int {
+    PRO_PLAIN = 0,  // activation rows used as they are
+    PRO_NORM = 1,   // fused RMSNorm (R/llama.R:65-72)
+    PRO_ATTN = 2,   // merge of the split-softmax attention partials
+};
+
 struct GemvArgs {
     const void* W = nullptr;      // [N, K] row-major (row = output feature), fp32 or bf16
     const float* x = nullptr;     // [rows, K]
@@ -30,6 +36,12 @@ struct GemvArgs {
     float* kcache = nullptr;      // this layer, these rows: [rows][H][max_len][64]
     float* vcache = nullptr;
     int n_heads = 0, max_len = 0;
+    // PRO_ATTN (o_proj): partials of attn_split_kernel; x is then unused
+    const float* pm = nullptr;    // [rows][H][n_split_max] running max
+    const float* pl = nullptr;    // [rows][H][n_split_max] sum of exp
+    const float* pacc = nullptr;  // [rows][H][n_split_max][64] unnormalised sum of exp * v
+    int n_split_max = 0, keys_per_split = 0;
+    int waves = 0;                // waves per block (0 = default 4)
 };
 
 struct AttnArgs {
@@ -37,8 +49,11 @@ struct AttnArgs {
     const float* kcache = nullptr;  // [rows][H][max_len][64]
     const float* vcache = nullptr;
     const int* rowpos = nullptr;  // [rows]; attends to positions 0..rowpos[r]
-    float* out = nullptr;         // [rows, H*64]
+    float* pm = nullptr;          // partial outputs, see GemvArgs
+    float* pl = nullptr;
+    float* pacc = nullptr;
     int rows = 0, n_heads = 0, max_len = 0;
+    int n_split_max = 0, keys_per_split = 64;
 };
 
 struct EmbedArgs {                // token-by-token prefill input (R/t3.R:494, :505)
@@ -72,6 +87,7 @@ struct SamplerArgs {
     int* dist_ids = nullptr;      // [n_utt, dist_cap] debug (may be nullptr)
     float* dist_probs = nullptr;
     int* dist_n = nullptr;
+    int* drawn = nullptr;         // [n_utt] token drawn before teacher forcing (debug)
     int dist_cap = 0;
 };
 

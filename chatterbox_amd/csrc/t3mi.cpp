@@ -68,10 +68,11 @@ struct LayerW {
 
 struct Session {
     int n_utt = 0, rpu = 1, rows = 0, max_len = 0, cap = 0, max_s0 = 0;
+    int kps = 64, n_split = 1;  // attention split: keys per block, blocks per (row, head)
     t3mi_params prm{};
     std::vector<int32_t> s0;
-    DevBuf kc, vc, x, qbuf, attn, hbuf, logits, rowpos, start, emb_rows, emb_data, seen, tokens, n_tokens,
-        done, s0_dev, forced, dist_ids, dist_probs, dist_n;
+    DevBuf kc, vc, x, qbuf, pm, pl, pacc, hbuf, logits, rowpos, start, emb_rows, emb_data, seen, tokens, n_tokens,
+        done, s0_dev, forced, dist_ids, dist_probs, dist_n, drawn;
     int n_forced = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
@@ -97,6 +98,7 @@ struct t3mi_model {
     int64_t weight_bytes = 0;
     std::unique_ptr<Session> sess;
     bool use_graph = true;
+    int tune[5] = {6, 4, 4, 4, 4};  // waves per block: qkv, o_proj, gate_up, down, head (T3MI_WAVES=a,b,c,d,e)
 };
 
 namespace {
@@ -253,6 +255,15 @@ int load_llama(t3mi_model* m, const t3mi::SafeTensorsFile& st) {
         if ((rc = up.put_w(p + "mlp.down_proj.weight", d, F, w))) return rc;
         w += d * F * es;
     }
+    if (const char* al = std::getenv("T3MI_DEBUG_ALIAS_LAYERS")) {
+        // measurement aid only (results are wrong): every layer streams layer 0's weights, so the
+        // whole working set stays in the 256 MiB Infinity Cache -- the chain's speed without HBM
+        if (al[0] == '1')
+            for (int l = 1; l < L; ++l) {
+                m->layers[l].wqkv = m->layers[0].wqkv; m->layers[l].wo = m->layers[0].wo;
+                m->layers[l].wgu = m->layers[0].wgu; m->layers[l].wdown = m->layers[0].wdown;
+            }
+    }
     m->norm_w = sm;
     if ((rc = up.put_f32("tfmr.norm.weight", d, -1, sm))) return rc;
     m->head_w = w;
@@ -300,24 +311,33 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.kcache = kc + (size_t)r0 * H * s->max_len * 64;
             a.vcache = vc + (size_t)r0 * H * s->max_len * 64;
             a.n_heads = H; a.max_len = s->max_len;
+            a.waves = m->tune[0];
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_ROPE_KV, m->wdtype, m->stream));
             r0 += rg;
         }
         if (tm) tm->mark(K_QKV);
-        // K2: attention over the cache
+        // K2: attention over the cache, split along the keys; partials merged in K3's prologue
         {
             t3k::AttnArgs a;
             a.q = s->qbuf.as<float>(); a.kcache = kc; a.vcache = vc; a.rowpos = s->rowpos.as<int>();
-            a.out = s->attn.as<float>(); a.rows = s->rows; a.n_heads = H; a.max_len = s->max_len;
+            a.pm = s->pm.as<float>(); a.pl = s->pl.as<float>(); a.pacc = s->pacc.as<float>();
+            a.rows = s->rows; a.n_heads = H; a.max_len = s->max_len;
+            a.n_split_max = s->n_split; a.keys_per_split = s->kps;
             HIPCHK(t3k::launch_attn_decode(a, m->stream));
         }
         if (tm) tm->mark(K_ATTN);
-        // K3: o_proj + residual
+        // K3: softmax-merge + o_proj + residual
         for (int r0 = 0; r0 < s->rows;) {
             const int rem = s->rows - r0, rg = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
             t3k::GemvArgs a;
-            a.W = lw.wo; a.x = s->attn.as<float>() + (size_t)r0 * d; a.N = d; a.K = d; a.rows = rg;
+            a.W = lw.wo; a.N = d; a.K = d; a.rows = rg;
+            a.pm = s->pm.as<float>() + (size_t)r0 * H * s->n_split;
+            a.pl = s->pl.as<float>() + (size_t)r0 * H * s->n_split;
+            a.pacc = s->pacc.as<float>() + (size_t)r0 * H * s->n_split * 64;
+            a.n_split_max = s->n_split; a.keys_per_split = s->kps;
+            a.rowpos = s->rowpos.as<int>() + r0;
             a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
+            a.waves = m->tune[1];
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
             r0 += rg;
         }
@@ -329,6 +349,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.W = lw.wgu; a.x = s->x.as<float>() + (size_t)r0 * d; a.ln_w = lw.ln2; a.eps = m->eps;
             a.N = 2 * F; a.K = d; a.rows = rg;
             a.y = s->hbuf.as<float>() + (size_t)r0 * F; a.ldy = F;
+            a.waves = m->tune[2];
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_SWIGLU, m->wdtype, m->stream));
             r0 += rg;
         }
@@ -339,6 +360,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             t3k::GemvArgs a;
             a.W = lw.wdown; a.x = s->hbuf.as<float>() + (size_t)r0 * F; a.N = d; a.K = F; a.rows = rg;
             a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
+            a.waves = m->tune[3];
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
             r0 += rg;
         }
@@ -355,6 +377,7 @@ int run_head(t3mi_model* m, Session* s, StepTimer* tm) {
         a.W = m->head_w; a.x = s->x.as<float>() + (size_t)r0 * d; a.ln_w = m->norm_w; a.eps = m->eps;
         a.N = m->V; a.K = d; a.rows = rg;
         a.y = s->logits.as<float>() + (size_t)r0 * m->V; a.ldy = m->V;
+        a.waves = m->tune[4];
         HIPCHK(t3k::launch_gemv(a, t3k::EPI_STORE, m->wdtype, m->stream));
         r0 += rg;
     }
@@ -376,6 +399,7 @@ int run_sampler(t3mi_model* m, Session* s, StepTimer* tm) {
     a.emb = m->emb.as<float>(); a.pos_emb = m->pos_emb.as<float>(); a.d = m->d; a.max_pos = m->max_pos;
     a.max_len = s->max_len; a.x = s->x.as<float>();
     a.dist_ids = s->dist_ids.as<int>(); a.dist_probs = s->dist_probs.as<float>(); a.dist_n = s->dist_n.as<int>();
+    a.drawn = s->drawn.as<int>();
     a.dist_cap = m->V;
     HIPCHK(t3k::launch_sampler(a, m->stream));
     if (tm) tm->mark(K_SAMPLER);
@@ -457,6 +481,12 @@ int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model*
     m->wdtype = wdtype;
     const char* g = std::getenv("T3MI_GRAPH");
     m->use_graph = !(g && g[0] == '0');
+    if (const char* tw = std::getenv("T3MI_WAVES")) {  // tuning knob, see DESIGN.md
+        int v[5];
+        if (std::sscanf(tw, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5)
+            for (int i = 0; i < 5; ++i)
+                if (v[i] >= 1 && v[i] <= 8) m->tune[i] = v[i];
+    }
     HIPCHK(t3k::init_device());
     HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     int rc = load_llama(m.get(), st);
@@ -559,7 +589,12 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     HIPCHK(s->vc.alloc(kv));
     HIPCHK(s->x.alloc(rows * d * 4));
     HIPCHK(s->qbuf.alloc(rows * d * 4));
-    HIPCHK(s->attn.alloc(rows * d * 4));
+    // attention split geometry: more blocks per (row, head) when few rows are live
+    s->kps = (rows * m->H <= 512) ? 64 : ((rows * m->H <= 2048) ? 128 : 256);
+    s->n_split = (s->max_len + s->kps - 1) / s->kps;
+    HIPCHK(s->pm.alloc(rows * m->H * (size_t)s->n_split * 4));
+    HIPCHK(s->pl.alloc(rows * m->H * (size_t)s->n_split * 4));
+    HIPCHK(s->pacc.alloc(rows * m->H * (size_t)s->n_split * 64 * 4));
     HIPCHK(s->hbuf.alloc(rows * F * 4));
     HIPCHK(s->logits.alloc(rows * V * 4));
     HIPCHK(s->rowpos.alloc(rows * 4));
@@ -573,13 +608,16 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     HIPCHK(s->dist_ids.alloc(U * V * 4));
     HIPCHK(s->dist_probs.alloc(U * V * 4));
     HIPCHK(s->dist_n.alloc(U * 4));
+    HIPCHK(s->drawn.alloc(U * 4));
     hipStream_t st = m->stream;
     // create_kv_cache zero-fills the slabs (R/llama_traced.R:276-283)
     HIPCHK(hipMemsetAsync(s->kc.p, 0, kv, st));
     HIPCHK(hipMemsetAsync(s->vc.p, 0, kv, st));
     HIPCHK(hipMemsetAsync(s->x.p, 0, rows * d * 4, st));
     HIPCHK(hipMemsetAsync(s->qbuf.p, 0, rows * d * 4, st));
-    HIPCHK(hipMemsetAsync(s->attn.p, 0, rows * d * 4, st));
+    HIPCHK(hipMemsetAsync(s->pm.p, 0, s->pm.bytes, st));
+    HIPCHK(hipMemsetAsync(s->pl.p, 0, s->pl.bytes, st));
+    HIPCHK(hipMemsetAsync(s->pacc.p, 0, s->pacc.bytes, st));
     HIPCHK(hipMemsetAsync(s->hbuf.p, 0, rows * F * 4, st));
     HIPCHK(hipMemsetAsync(s->logits.p, 0, rows * V * 4, st));
     HIPCHK(hipMemsetAsync(s->seen.p, 0, U * V, st));
@@ -752,6 +790,17 @@ int t3mi_session_dist(t3mi_model* m, int utt, int32_t* ids, float* probs, int32_
         HIPCHK(hipMemcpy(ids, s->dist_ids.as<int>() + (size_t)utt * m->V, (size_t)k * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(probs, s->dist_probs.as<float>() + (size_t)utt * m->V, (size_t)k * 4, hipMemcpyDeviceToHost));
     }
+    return T3MI_OK;
+}
+
+int t3mi_session_drawn(t3mi_model* m, int32_t* drawn) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    if (!drawn) return fail(T3MI_ERR_ARG, "null out");
+    Session* s = m->sess.get();
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(drawn, s->drawn.p, (size_t)s->n_utt * 4, hipMemcpyDeviceToHost));
     return T3MI_OK;
 }
 

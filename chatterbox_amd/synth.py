@@ -38,7 +38,9 @@ TINY = T3Dims(hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
               start_speech_token=990, stop_speech_token=991)
 
 
-def synth_llama_weights(dims: T3Dims, seed: int = 1234) -> Dict[str, np.ndarray]:
+def synth_llama_weights(dims: T3Dims, seed: int = 1234, head_scale: float = 1.0) -> Dict[str, np.ndarray]:
+    """head_scale > 1 widens the speech-head weights so the next-token distribution is peaked
+    like a trained model's (tens of tokens above min-p) instead of nearly flat."""
     rng = np.random.Generator(np.random.PCG64(seed))
     d, F, V = dims.hidden_size, dims.intermediate_size, dims.speech_vocab
 
@@ -64,6 +66,8 @@ def synth_llama_weights(dims: T3Dims, seed: int = 1234) -> Dict[str, np.ndarray]
     w["speech_emb.weight"] = lin(V, d)
     w["speech_pos_emb.emb.weight"] = lin(dims.max_speech_pos, d)
     w["speech_head.weight"] = lin(V, d)
+    if head_scale != 1.0:
+        w["speech_head.weight"] = (w["speech_head.weight"] * F32(head_scale)).astype(F32)
     return w
 
 
@@ -99,16 +103,17 @@ def write_safetensors(weights: Dict[str, np.ndarray], path: str) -> str:
     return path
 
 
-def checkpoint_path(dims: T3Dims, seed: int = 1234, root: str | None = None) -> str:
+def checkpoint_path(dims: T3Dims, seed: int = 1234, root: str | None = None, head_scale: float = 1.0) -> str:
     root = root or os.environ.get("T3MI_SYNTH_DIR", "/tmp/t3mi_synth")
     os.makedirs(root, exist_ok=True)
-    tag = f"t3_L{dims.num_hidden_layers}_d{dims.hidden_size}_F{dims.intermediate_size}_V{dims.speech_vocab}_s{seed}"
+    tag = f"t3_L{dims.num_hidden_layers}_d{dims.hidden_size}_F{dims.intermediate_size}_V{dims.speech_vocab}_s{seed}" + (
+        "" if head_scale == 1.0 else f"_h{head_scale:g}")
     return os.path.join(root, tag + ".safetensors")
 
 
-def ensure_checkpoint(dims: T3Dims, seed: int = 1234, root: str | None = None) -> str:
+def ensure_checkpoint(dims: T3Dims, seed: int = 1234, root: str | None = None, head_scale: float = 1.0) -> str:
     """Create the synthetic checkpoint file once and return its path."""
-    path = checkpoint_path(dims, seed, root)
+    path = checkpoint_path(dims, seed, root, head_scale)
     if not os.path.exists(path):
-        write_safetensors(synth_llama_weights(dims, seed), path)
+        write_safetensors(synth_llama_weights(dims, seed, head_scale), path)
     return path

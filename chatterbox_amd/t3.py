@@ -230,6 +230,11 @@ class Session:
             pr.ctypes.data_as(C.POINTER(C.c_float)), V, C.byref(n)))
         return ids[: n.value].astype(np.int64), pr[: n.value].copy()
 
+    def drawn(self) -> np.ndarray:
+        out = (C.c_int32 * self.n_utt)()
+        _lib.check(self.model._lib.t3mi_session_drawn(self.model._h, out))
+        return np.array(out[:], dtype=np.int64)
+
     def profile_step(self):
         st = (_lib.KStat * 16)()
         n = C.c_int(0)

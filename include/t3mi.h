@@ -135,6 +135,9 @@ int t3mi_session_logits(t3mi_model* m, float* out);
 /* Final filtered distribution of utterance `utt` at the most recent step: ids in descending
  * probability, their renormalised probabilities; *n = support size (parity hook). */
 int t3mi_session_dist(t3mi_model* m, int utt, int32_t* ids, float* probs, int32_t cap, int32_t* n);
+/* drawn[u] = the token utterance u's sampler drew at the most recent step BEFORE teacher forcing
+ * replaced it (parity hook for the draw itself). */
+int t3mi_session_drawn(t3mi_model* m, int32_t* drawn);
 /* Time every kernel of ONE decode step with HIP events (advances the session by one step). */
 int t3mi_session_profile_step(t3mi_model* m, t3mi_kstat* stats, int cap, int* n_stats);
 int t3mi_session_end(t3mi_model* m);

@@ -309,6 +309,8 @@ class TailResult:
     sorted_idx: np.ndarray           # descending-prob order, 0-indexed ids (support only)
     sorted_probs: np.ndarray         # final renormalised probs of the support (float32)
     logits_after_temp: np.ndarray    # [V]
+    cum: Optional[np.ndarray] = None  # float32 cumsum over the kept prefix
+    target: float = 0.0              # u * cum[-1] (float32) of the draw
 
 
 def sampling_tail(logits_cfg: np.ndarray, seen0: Sequence[int], p: SampleParams,
@@ -346,7 +348,7 @@ def sampling_tail(logits_cfg: np.ndarray, seen0: Sequence[int], p: SampleParams,
     target = F32(F32(u) * cum[nz - 1])
     j = int(np.count_nonzero(cum[:nz] <= target))
     j = min(j, nz - 1)
-    return TailResult(int(sup_idx[j]), sup_idx, sup_p, lg)
+    return TailResult(int(sup_idx[j]), sup_idx, sup_p, lg, cum[:nz].copy(), float(target))
 
 
 # --------------------------------------------------------------------------
