@@ -86,8 +86,8 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
     constexpr int K = KW * KSPLIT;
     static_assert(EPI == EPI_STORE || EPI == EPI_RESID || (ROWS % 2 == 0), "paired epilogues need even ROWS");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;                       // [R][K]
-    float* part = smem + R * K;             // [NW][ROWS][R] (KSPLIT > 1) / reduction scratch
+    float* xs = smem;                                          // [R][K], PRO_ATTN only
+    float* part = smem + (PRO == PRO_ATTN ? R * K : 0);        // [NW][ROWS][R] (KSPLIT > 1)
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
     const int grp = wave / KSPLIT, kpart = wave % KSPLIT, ngrp = nw / KSPLIT;
@@ -111,41 +111,36 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
     };
     if (c < n_chunks) load_chunk(c);
 
-    // ---- prologue: activation rows -> LDS
-    if (PRO == PRO_PLAIN) {
-        for (int i = tid * 4; i < R * K; i += nthr * 4)
-            *reinterpret_cast<float4*>(xs + i) = *reinterpret_cast<const float4*>(a.x + i);
-    } else if (PRO == PRO_NORM) {
-        float ss[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float t = 0.f;
-            for (int i = tid * 4; i < K; i += nthr * 4) {
-                const float4 v = *reinterpret_cast<const float4*>(a.x + (size_t)r * K + i);
-                t = fmaf(v.x, v.x, t); t = fmaf(v.y, v.y, t); t = fmaf(v.z, v.z, t); t = fmaf(v.w, v.w, t);
+    // Epilogue operands that do not depend on the GEMV (cache position, RoPE row, residual) are
+    // requested now, so the tail of the kernel is reduce -> store with no dependent global load.
+    int e_pos = -1;
+    float e_c = 0.f, e_s = 0.f, e_res = 0.f;
+    {
+        constexpr int HP = ROWS / 2;
+        if (EPI == EPI_ROPE_KV) {
+            if (lane < HP * R) {
+                e_pos = a.rowpos[lane % R];
+                if (e_pos >= 0 && c < n_chunks) {
+                    const int per_head = 32 / HP;
+                    const int i = (c % per_head) * HP + lane / R;   // rotate_half pair index 0..31
+                    e_c = a.rope_cos[(size_t)e_pos * kHeadDim + i];  // cos[i] == cos[i+32] (emb = cat(freqs, freqs))
+                    e_s = a.rope_sin[(size_t)e_pos * kHeadDim + i];
+                }
             }
-            ss[r] = wave_sum(t);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) part[wave * R + r] = ss[r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float t = 0.f;
-            for (int ww = 0; ww < nw; ++ww) t += part[ww * R + r];
-            const float rs = 1.0f / sqrtf(t / (float)K + a.eps);
-            for (int i = tid * 4; i < K; i += nthr * 4) {
-                const float4 v = *reinterpret_cast<const float4*>(a.x + (size_t)r * K + i);
-                const float4 g = *reinterpret_cast<const float4*>(a.ln_w + i);
-                float4 o;
-                o.x = __fmul_rn(g.x, __fmul_rn(v.x, rs)); o.y = __fmul_rn(g.y, __fmul_rn(v.y, rs));
-                o.z = __fmul_rn(g.z, __fmul_rn(v.z, rs)); o.w = __fmul_rn(g.w, __fmul_rn(v.w, rs));
-                *reinterpret_cast<float4*>(xs + r * K + i) = o;
+        } else if (EPI == EPI_RESID) {
+            if (lane < ROWS * R && c < n_chunks && (KSPLIT == 1 || kpart == 0)) {
+                const int n = ROWS * c + lane / R;
+                if (n < a.N) e_res = a.resid[(size_t)(lane % R) * a.ldy + n];
             }
         }
-    } else {  // PRO_ATTN: softmax-merge the per-split partials (attn_split_kernel)
+    }
+
+    // ---- prologue: this lane's k-slice of the activation rows.  PLAIN / NORM read straight from
+    // global memory per wave (one L2 round trip, no barrier on the critical path; the redundant norm
+    // per wave is cheaper than a block-wide exchange); ATTN merges the split-softmax partials once
+    // per block through LDS.
+    float xv[R][NK][E];
+    if (PRO == PRO_ATTN) {
         const int H = K / kHeadDim;
         for (int idx = tid; idx < R * (K / 4); idx += nthr) {
             const int r = idx / (K / 4), k4 = idx % (K / 4);
@@ -169,19 +164,52 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
             }
             *reinterpret_cast<float4*>(xs + r * K + k4 * 4) = o;
         }
-    }
-    __syncthreads();
-
-    float xv[R][NK][E];
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int q = 0; q < NK; ++q)
+            for (int q = 0; q < NK; ++q)
 #pragma unroll
-            for (int e4 = 0; e4 < E; e4 += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(xs + r * K + kbase + q * kWave * E + lane * E + e4);
-                xv[r][q][e4 + 0] = v.x; xv[r][q][e4 + 1] = v.y; xv[r][q][e4 + 2] = v.z; xv[r][q][e4 + 3] = v.w;
+                for (int e4 = 0; e4 < E; e4 += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(xs + r * K + kbase + q * kWave * E + lane * E + e4);
+                    xv[r][q][e4 + 0] = v.x; xv[r][q][e4 + 1] = v.y; xv[r][q][e4 + 2] = v.z; xv[r][q][e4 + 3] = v.w;
+                }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < NK; ++q)
+#pragma unroll
+                for (int e4 = 0; e4 < E; e4 += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(a.x + (size_t)r * K + kbase + q * kWave * E + lane * E + e4);
+                    xv[r][q][e4 + 0] = v.x; xv[r][q][e4 + 1] = v.y; xv[r][q][e4 + 2] = v.z; xv[r][q][e4 + 3] = v.w;
+                }
+        if (PRO == PRO_NORM) {
+            static_assert(PRO != PRO_NORM || KSPLIT == 1, "norm prologue needs the whole row in one wave");
+            float lw[NK][E];
+#pragma unroll
+            for (int q = 0; q < NK; ++q)
+#pragma unroll
+                for (int e4 = 0; e4 < E; e4 += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(a.ln_w + q * kWave * E + lane * E + e4);
+                    lw[q][e4 + 0] = v.x; lw[q][e4 + 1] = v.y; lw[q][e4 + 2] = v.z; lw[q][e4 + 3] = v.w;
+                }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float ss = 0.f;
+#pragma unroll
+                for (int q = 0; q < NK; ++q)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) ss = fmaf(xv[r][q][e], xv[r][q][e], ss);
+                ss = wave_sum(ss);
+                const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
+#pragma unroll
+                for (int q = 0; q < NK; ++q)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) xv[r][q][e] = __fmul_rn(lw[q][e], __fmul_rn(xv[r][q][e], rs));
             }
+        }
+    }
 
     for (; cb < n_chunks; cb += cstride, c += cstride) {
         const bool live = c < n_chunks;
@@ -228,6 +256,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
         if (!live) continue;
 
         if (EPI == EPI_STORE || EPI == EPI_RESID) {
+            const bool first = (cb == (int)blockIdx.x * ngrp);
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
 #pragma unroll
@@ -236,7 +265,12 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
                         const int n = ROWS * c + j;
                         if (n < a.N) {
                             const size_t o = (size_t)r * a.ldy + n;
-                            a.y[o] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o], acc[j][r]) : acc[j][r];
+                            if (EPI == EPI_RESID) {
+                                const float res = first ? e_res : a.resid[o];
+                                a.y[o] = __fadd_rn(res, acc[j][r]);
+                            } else {
+                                a.y[o] = acc[j][r];
+                            }
                         }
                     }
         } else if (EPI == EPI_SWIGLU) {
@@ -257,23 +291,23 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
             const int per_head = 32 / HP;
             const int hm = c / per_head, i0 = (c % per_head) * HP;
             const int kind = hm / H, head = hm % H;  // 0 q, 1 k, 2 v
+            const bool first = (cb == (int)blockIdx.x * ngrp);
 #pragma unroll
             for (int jj = 0; jj < HP; ++jj)
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     if (lane == jj * R + r) {
-                        const int pos = a.rowpos[r];
+                        const int pos = e_pos;
                         if (pos >= 0) {
                             const int i = i0 + jj;
                             float lo = acc[jj][r], hi = acc[jj + HP][r];
                             if (kind < 2) {
-                                // q*cos + rotate_half(q)*sin, each product rounded (R/llama.R:184-185)
-                                const float cl = a.rope_cos[(size_t)pos * kHeadDim + i];
-                                const float sl = a.rope_sin[(size_t)pos * kHeadDim + i];
-                                const float ch = a.rope_cos[(size_t)pos * kHeadDim + i + 32];
-                                const float sh = a.rope_sin[(size_t)pos * kHeadDim + i + 32];
-                                const float nlo = __fadd_rn(__fmul_rn(lo, cl), __fmul_rn(-hi, sl));
-                                const float nhi = __fadd_rn(__fmul_rn(hi, ch), __fmul_rn(lo, sh));
+                                // q*cos + rotate_half(q)*sin, each product rounded (R/llama.R:184-185);
+                                // cos/sin rows repeat with period 32, so one (cos, sin) serves both halves
+                                const float cs = first ? e_c : a.rope_cos[(size_t)pos * kHeadDim + i];
+                                const float sn = first ? e_s : a.rope_sin[(size_t)pos * kHeadDim + i];
+                                const float nlo = __fadd_rn(__fmul_rn(lo, cs), __fmul_rn(-hi, sn));
+                                const float nhi = __fadd_rn(__fmul_rn(hi, cs), __fmul_rn(lo, sn));
                                 lo = nlo; hi = nhi;
                             }
                             if (kind == 0) {
@@ -692,7 +726,7 @@ hipError_t launch_gemv_t(const GemvArgs& a, hipStream_t s) {
     const int per_block = nw / KSPLIT;
     int grid = (n_chunks + per_block - 1) / per_block;
     if (grid > 256 * 8) grid = 256 * 8;
-    const size_t lds = ((size_t)R * K + (size_t)nw * ROWS * R + 32) * sizeof(float);
+    const size_t lds = ((PRO == PRO_ATTN ? (size_t)R * K : 0) + (size_t)nw * ROWS * R + 32) * sizeof(float);
     auto kfn = gemv_kernel<WT, R, NK, KSPLIT, ROWS, EPI, PRO>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -705,16 +739,29 @@ hipError_t launch_gemv_t(const GemvArgs& a, hipStream_t s) {
 
 template <typename WT, int R, int NK>
 hipError_t launch_gemv_rn(const GemvArgs& a, int epi, int ksplit, hipStream_t s) {
+    const int rpc = a.rows_per_chunk;
     if (ksplit == 1) {
         switch (epi) {
-            case EPI_STORE: return launch_gemv_t<WT, R, NK, 1, 4, EPI_STORE, PRO_NORM>(a, s);
-            case EPI_ROPE_KV: return launch_gemv_t<WT, R, NK, 1, 2, EPI_ROPE_KV, PRO_NORM>(a, s);
-            case EPI_SWIGLU: return launch_gemv_t<WT, R, NK, 1, 4, EPI_SWIGLU, PRO_NORM>(a, s);
+            case EPI_STORE:
+                if (rpc == 1) return launch_gemv_t<WT, R, NK, 1, 1, EPI_STORE, PRO_NORM>(a, s);
+                if (rpc == 2) return launch_gemv_t<WT, R, NK, 1, 2, EPI_STORE, PRO_NORM>(a, s);
+                return launch_gemv_t<WT, R, NK, 1, 4, EPI_STORE, PRO_NORM>(a, s);
+            case EPI_ROPE_KV:
+                if (rpc == 4) return launch_gemv_t<WT, R, NK, 1, 4, EPI_ROPE_KV, PRO_NORM>(a, s);
+                return launch_gemv_t<WT, R, NK, 1, 2, EPI_ROPE_KV, PRO_NORM>(a, s);
+            case EPI_SWIGLU:
+                if (rpc == 4) return launch_gemv_t<WT, R, NK, 1, 4, EPI_SWIGLU, PRO_NORM>(a, s);
+                return launch_gemv_t<WT, R, NK, 1, 2, EPI_SWIGLU, PRO_NORM>(a, s);
             case EPI_RESID:
-                if (a.pacc != nullptr) return launch_gemv_t<WT, R, NK, 1, 1, EPI_RESID, PRO_ATTN>(a, s);
+                if (a.pacc != nullptr) {
+                    if (rpc == 2) return launch_gemv_t<WT, R, NK, 1, 2, EPI_RESID, PRO_ATTN>(a, s);
+                    return launch_gemv_t<WT, R, NK, 1, 1, EPI_RESID, PRO_ATTN>(a, s);
+                }
                 return launch_gemv_t<WT, R, NK, 1, 1, EPI_RESID, PRO_PLAIN>(a, s);
         }
     } else if (ksplit == 4 && epi == EPI_RESID && a.pacc == nullptr) {
+        if (rpc == 1) return launch_gemv_t<WT, R, NK, 4, 1, EPI_RESID, PRO_PLAIN>(a, s);
+        if (rpc == 2) return launch_gemv_t<WT, R, NK, 4, 2, EPI_RESID, PRO_PLAIN>(a, s);
         return launch_gemv_t<WT, R, NK, 4, 4, EPI_RESID, PRO_PLAIN>(a, s);
     }
     return hipErrorInvalidValue;
@@ -767,7 +814,7 @@ hipError_t launch_gemv(const GemvArgs& a, int epilogue, int wdtype, hipStream_t 
             return hipErrorInvalidValue;
         }
     }
-    if (epilogue == EPI_SWIGLU && (a.N % 4)) return hipErrorInvalidValue;
+    if (epilogue == EPI_SWIGLU && (a.N % 8)) return hipErrorInvalidValue;
     if (epilogue == EPI_ROPE_KV) {
         if (a.N != 3 * a.n_heads * kHeadDim || a.rowpos == nullptr || a.kcache == nullptr ||
             a.vcache == nullptr || a.rope_cos == nullptr || a.rope_sin == nullptr || a.max_len <= 0)

@@ -42,6 +42,7 @@ struct GemvArgs {
     const float* pacc = nullptr;  // [rows][H][n_split_max][64] unnormalised sum of exp * v
     int n_split_max = 0, keys_per_split = 0;
     int waves = 0;                // waves per block (0 = default 4)
+    int rows_per_chunk = 0;       // output features per wave-chunk (0 = kernel default)
 };
 
 struct AttnArgs {

@@ -98,7 +98,8 @@ struct t3mi_model {
     int64_t weight_bytes = 0;
     std::unique_ptr<Session> sess;
     bool use_graph = true;
-    int tune[5] = {6, 4, 4, 4, 4};  // waves per block: qkv, o_proj, gate_up, down, head (T3MI_WAVES=a,b,c,d,e)
+    int tune[5] = {4, 4, 4, 4, 4};  // waves per block: qkv, o_proj, gate_up, down, head (T3MI_WAVES=a,b,c,d,e)
+    int tune_rows[5] = {2, 1, 2, 2, 2};  // output rows per wave-chunk, same order (T3MI_ROWS=a,b,c,d,e)
 };
 
 namespace {
@@ -311,7 +312,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.kcache = kc + (size_t)r0 * H * s->max_len * 64;
             a.vcache = vc + (size_t)r0 * H * s->max_len * 64;
             a.n_heads = H; a.max_len = s->max_len;
-            a.waves = m->tune[0];
+            a.waves = m->tune[0]; a.rows_per_chunk = m->tune_rows[0];
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_ROPE_KV, m->wdtype, m->stream));
             r0 += rg;
         }
@@ -337,7 +338,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.n_split_max = s->n_split; a.keys_per_split = s->kps;
             a.rowpos = s->rowpos.as<int>() + r0;
             a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
-            a.waves = m->tune[1];
+            a.waves = m->tune[1]; a.rows_per_chunk = m->tune_rows[1];
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
             r0 += rg;
         }
@@ -349,7 +350,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.W = lw.wgu; a.x = s->x.as<float>() + (size_t)r0 * d; a.ln_w = lw.ln2; a.eps = m->eps;
             a.N = 2 * F; a.K = d; a.rows = rg;
             a.y = s->hbuf.as<float>() + (size_t)r0 * F; a.ldy = F;
-            a.waves = m->tune[2];
+            a.waves = m->tune[2]; a.rows_per_chunk = m->tune_rows[2];
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_SWIGLU, m->wdtype, m->stream));
             r0 += rg;
         }
@@ -360,7 +361,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             t3k::GemvArgs a;
             a.W = lw.wdown; a.x = s->hbuf.as<float>() + (size_t)r0 * F; a.N = d; a.K = F; a.rows = rg;
             a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
-            a.waves = m->tune[3];
+            a.waves = m->tune[3]; a.rows_per_chunk = m->tune_rows[3];
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
             r0 += rg;
         }
@@ -377,7 +378,7 @@ int run_head(t3mi_model* m, Session* s, StepTimer* tm) {
         a.W = m->head_w; a.x = s->x.as<float>() + (size_t)r0 * d; a.ln_w = m->norm_w; a.eps = m->eps;
         a.N = m->V; a.K = d; a.rows = rg;
         a.y = s->logits.as<float>() + (size_t)r0 * m->V; a.ldy = m->V;
-        a.waves = m->tune[4];
+        a.waves = m->tune[4]; a.rows_per_chunk = m->tune_rows[4];
         HIPCHK(t3k::launch_gemv(a, t3k::EPI_STORE, m->wdtype, m->stream));
         r0 += rg;
     }
@@ -486,6 +487,12 @@ int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model*
         if (std::sscanf(tw, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5)
             for (int i = 0; i < 5; ++i)
                 if (v[i] >= 1 && v[i] <= 8) m->tune[i] = v[i];
+    }
+    if (const char* tr = std::getenv("T3MI_ROWS")) {
+        int v[5];
+        if (std::sscanf(tr, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5)
+            for (int i = 0; i < 5; ++i)
+                if (v[i] == 1 || v[i] == 2 || v[i] == 4) m->tune_rows[i] = v[i];
     }
     HIPCHK(t3k::init_device());
     HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
