@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--utterances", type=int, default=1, help="utterances per GPU (1 = configs[1])")
     ap.add_argument("--s0", type=int, default=52)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="weight storage type")
-    ap.add_argument("--cpu-steps", type=int, default=40, help="decode steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=600, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args()
 
@@ -165,6 +165,17 @@ def main():
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "bytes_per_launch": int(bstep), "avg_launch_us": round(step_us, 2)}
+    # HBM traffic per step from the committed rocprofv3 PMC passes of this same command
+    # (scripts/profile_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); bench.py cannot run
+    # the profiler on itself, so the number is only attached when the workload matches.
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        wl = tj.get("workload", {})
+        if wl.get("dtype") == args.dtype and wl.get("utterances_per_gpu") == U and wl.get("s0") == args.s0:
+            roof["traffic"] = int(tj["hbm_bytes_per_step"])
+            roof["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " + str(wl.get("steps")) + ")"
+    except Exception:
+        pass
     if not args.no_profile and rank == 0:
         try:
             acc = {}

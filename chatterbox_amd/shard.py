@@ -1,0 +1,49 @@
+"""Utterance-level sharding over the GPUs of one node.
+
+Each utterance (its CFG row pair, KV cache, penalty set and RNG stream) is independent, so the
+path shards with NO data-path collective: weights are replicated (2.05 GB fp32 of 288 GB HBM),
+utterance u goes to rank floor(u * G / U) (contiguous blocks), every rank decodes its block with
+its own t3mi handle, and the only exchange is the host-side gather of int token vectors in
+utterance order.  One process per GPU (`torch.distributed`; backend "nccl" = RCCL on the GPU
+box, "gloo" in the CPU tests) -- the collectives carry results only, never activations.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence
+
+import numpy as np
+
+
+def owner(u: int, n_utt: int, world: int) -> int:
+    """Rank that decodes utterance u: floor(u * G / U)."""
+    return (u * world) // n_utt
+
+
+def local_indices(n_utt: int, world: int, rank: int) -> List[int]:
+    return [u for u in range(n_utt) if owner(u, n_utt, world) == rank]
+
+
+def decode_sharded(decode_fn: Callable[[Sequence[int]], List[np.ndarray]], n_utt: int, world: int, rank: int,
+                   dist=None) -> List[np.ndarray]:
+    """Run `decode_fn(my_utterance_ids) -> [tokens per utterance]` on this rank's block and
+    return ALL utterances' tokens in utterance order on every rank.  `dist` is an initialised
+    torch.distributed module (or None for a single process)."""
+    mine = local_indices(n_utt, world, rank)
+    outs = decode_fn(mine) if mine else []
+    if len(outs) != len(mine):
+        raise RuntimeError("decode_fn returned the wrong number of utterances")
+    local = [(u, np.asarray(t, dtype=np.int64)) for u, t in zip(mine, outs)]
+    if dist is None or world == 1:
+        gathered = [local]
+    else:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+    result: List[np.ndarray] = [np.zeros(0, np.int64)] * n_utt
+    seen = 0
+    for part in gathered:
+        for u, t in part:
+            result[u] = t
+            seen += 1
+    if seen != n_utt:
+        raise RuntimeError(f"gathered {seen} utterances, expected {n_utt}")
+    return result

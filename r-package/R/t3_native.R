@@ -1,0 +1,78 @@
+# MI355X-native T3 decode behind the reference's R API.
+# Drop this file into the package's R/ directory (it replaces the bodies of t3_inference /
+# t3_inference_cpp, R/t3.R:461-605, 932-1050; signatures and return values are unchanged) and add
+#     useDynLib(chatterbox, .registration = TRUE)
+# to NAMESPACE (missing in the reference, SURVEY Q18).
+
+.t3mi <- new.env(parent = emptyenv())
+
+#' Open (once) the native model for the safetensors file the R model was loaded from.
+t3mi_model <- function (path, device = 0L, dtype = c("f32", "bf16"))
+{
+    dtype <- match.arg(dtype)
+    key <- paste(normalizePath(path), device, dtype)
+    if (is.null(.t3mi[[key]])) {
+        .t3mi[[key]] <- .Call("t3mi_r_open", path, 0L, as.integer(device),
+                              if (dtype == "bf16") 1L else 0L, PACKAGE = "chatterbox")
+    }
+    .t3mi[[key]]
+}
+
+.t3mi_decode <- function (model, cond, text_tokens, cfg, native, sampler, max_cache_len = 0L)
+{
+    config <- model$config
+    device <- model$text_emb$weight$device
+    if (text_tokens$dim() == 1) text_tokens <- text_tokens$unsqueeze(1)
+    # prompt construction stays in R torch until SURVEY f1 lands (R/t3.R:474-495)
+    text_tokens <- torch::nnf_pad(text_tokens, c(1, 0), value = config$start_text_token)
+    text_tokens <- torch::nnf_pad(text_tokens, c(0, 1), value = config$stop_text_token)
+    bos <- torch::torch_tensor(matrix(config$start_speech_token, nrow = 1), device = device,
+                               dtype = torch::torch_long())
+    if (cfg$cfg_weight > 0) {
+        text_tokens <- torch::torch_cat(list(text_tokens, text_tokens), dim = 1)
+        bos <- torch::torch_cat(list(bos, bos), dim = 1)
+    }
+    embeds <- torch::with_no_grad(model$prepare_input_embeds(cond, text_tokens, bos, cfg$cfg_weight)$embeds)
+    e <- as.array(embeds$to(device = "cpu", dtype = torch::torch_float32()))   # [rows, S0, d], column-major
+    cfg$stop_token <- as.integer(config$stop_speech_token)
+    cfg$start_token <- as.integer(config$start_speech_token)
+    cfg$sampler <- as.integer(sampler)
+    cfg$max_cache_len <- as.integer(max_cache_len)
+    ids <- .Call("t3mi_r_generate", native, e, as.integer(dim(e)), cfg, PACKAGE = "chatterbox")
+    list(ids = ids, device = device, stop = config$stop_speech_token)
+}
+
+#' Same signature and return value as the reference's t3_inference (R/t3.R:461-463, 598-604).
+t3_inference <- function (model, cond, text_tokens, max_new_tokens = 1000,
+                          temperature = 0.8, cfg_weight = 0.5, top_p = 0.95,
+                          min_p = 0.05, repetition_penalty = 1.2,
+                          native = t3mi_model(attr(model, "t3_path")))
+{
+    cfg <- list(max_tokens = as.integer(max_new_tokens), temperature = as.double(temperature),
+                cfg_weight = as.double(cfg_weight), top_p = as.double(top_p), min_p = as.double(min_p),
+                rep_penalty = as.double(repetition_penalty))
+    r <- .t3mi_decode(model, cond, text_tokens, cfg, native, sampler = 0L)
+    if (length(r$ids) && r$ids[length(r$ids)] == r$stop) message("EOS detected at step ", length(r$ids))
+    if (length(r$ids) > 0) torch::torch_tensor(r$ids, dtype = torch::torch_long(), device = r$device)
+    else torch::torch_tensor(integer(0), device = r$device)
+}
+
+#' Same signature and return value as t3_inference_cpp (R/t3.R:932-935, 1039-1049).
+t3_inference_cpp <- function (model, cond, text_tokens, max_new_tokens = 1000,
+                              temperature = 0.8, cfg_weight = 0.5, top_p = 0.95,
+                              min_p = 0.05, repetition_penalty = 1.2, max_cache_len = 350L,
+                              native = t3mi_model(attr(model, "t3_path")))
+{
+    cfg <- list(max_tokens = as.integer(max_new_tokens), temperature = as.double(temperature),
+                cfg_weight = as.double(cfg_weight), top_p = as.double(top_p), min_p = as.double(min_p),
+                rep_penalty = as.double(repetition_penalty))
+    r <- .t3mi_decode(model, cond, text_tokens, cfg, native, sampler = 1L, max_cache_len = max_cache_len)
+    ids <- r$ids
+    eos <- match(r$stop, ids)
+    if (!is.na(eos)) {
+        message("EOS detected at step ", eos)
+        ids <- ids[seq_len(eos - 1L)]
+    }
+    if (length(ids) > 0L) torch::torch_tensor(ids, dtype = torch::torch_long(), device = r$device)
+    else torch::torch_tensor(integer(0), device = r$device)
+}

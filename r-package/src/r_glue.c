@@ -1,0 +1,175 @@
+/* R glue for libt3mi: the .Call entry points that replace
+ *     SEXP cpp_t3_decode(SEXP x 11)            /root/reference src/t3_decode.cpp:207-219
+ *     registered in R_init_chatterbox           /root/reference src/init.c:5-15
+ * The reference passes R-torch external pointers (src/t3_decode.cpp:26-32); here the model is
+ * an external pointer to a t3mi handle that owns its weights in HBM, the prompt is a plain
+ * numeric array, and the decode parameters are the SAME named list the reference builds at
+ * R/t3.R:1022-1034 (read by name, like src/t3_decode.cpp:43-64, 221-231).
+ *
+ * Not compiled in the build container (no R headers there); compiled by the package's
+ * `configure` + R CMD INSTALL on a machine with R and ROCm.  Plain C, R API only.
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "t3mi.h"
+
+static double cfg_real(SEXP list, const char* name, double dflt, int required) {
+    SEXP names = Rf_getAttrib(list, R_NamesSymbol);
+    if (names != R_NilValue)
+        for (R_xlen_t i = 0; i < Rf_xlength(list); i++)
+            if (strcmp(CHAR(STRING_ELT(names, i)), name) == 0) return Rf_asReal(VECTOR_ELT(list, i));
+    if (required) Rf_error("Missing config parameter: %s", name); /* same text as src/t3_decode.cpp:50 */
+    return dflt;
+}
+
+static void model_finalizer(SEXP ptr) {
+    t3mi_model* m = (t3mi_model*)R_ExternalPtrAddr(ptr);
+    if (m) {
+        t3mi_close(m);
+        R_ClearExternalPtr(ptr);
+    }
+}
+
+static t3mi_model* get_model(SEXP ptr) {
+    if (TYPEOF(ptr) != EXTPTRSXP) Rf_error("t3mi: not a model handle");
+    t3mi_model* m = (t3mi_model*)R_ExternalPtrAddr(ptr);
+    if (!m) Rf_error("t3mi: model handle was closed");
+    return m;
+}
+
+/* .Call("t3mi_r_open", path, variant, device, dtype) -> external pointer */
+SEXP t3mi_r_open(SEXP path, SEXP variant, SEXP device, SEXP dtype) {
+    t3mi_model* m = NULL;
+    int rc = t3mi_open(CHAR(STRING_ELT(path, 0)), Rf_asInteger(variant), Rf_asInteger(device),
+                       Rf_asInteger(dtype), &m);
+    if (rc != T3MI_OK) Rf_error("t3mi_open: %s", t3mi_last_error());
+    SEXP ptr = PROTECT(R_MakeExternalPtr(m, R_NilValue, R_NilValue));
+    R_RegisterCFinalizerEx(ptr, model_finalizer, TRUE);
+    UNPROTECT(1);
+    return ptr;
+}
+
+SEXP t3mi_r_close(SEXP ptr) {
+    model_finalizer(ptr);
+    return R_NilValue;
+}
+
+static void fill_params(SEXP cfg, t3mi_params* p) {
+    t3mi_default_params(p);
+    /* names of the reference's list (R/t3.R:1022-1034); cond_len / n_heads / head_dim / rms_eps are
+     * properties of the prompt and the checkpoint here and are accepted but not needed */
+    p->max_new_tokens = (int32_t)cfg_real(cfg, "max_tokens", 1000, 1);
+    p->temperature = (float)cfg_real(cfg, "temperature", 0.8, 1);
+    p->cfg_weight = (float)cfg_real(cfg, "cfg_weight", 0.5, 1);
+    p->top_p = (float)cfg_real(cfg, "top_p", 0.95, 1);
+    p->min_p = (float)cfg_real(cfg, "min_p", 0.05, 1);
+    p->repetition_penalty = (float)cfg_real(cfg, "rep_penalty", 1.2, 1);
+    p->stop_token = (int32_t)cfg_real(cfg, "stop_token", 6562, 1);
+    p->start_token = (int32_t)cfg_real(cfg, "start_token", 6561, 0);
+    p->sampler = (int32_t)cfg_real(cfg, "sampler", T3MI_SAMPLER_R, 0);
+    p->max_cache_len = (int32_t)cfg_real(cfg, "max_cache_len", 0, 0);
+    p->seed = (uint64_t)cfg_real(cfg, "seed", 0, 0);
+}
+
+/* R arrays are column-major doubles: embeds[r, t, k] sits at r + rows*(t + s0*k). */
+static float* to_row_major(SEXP embeds, int rows, int s0, int d) {
+    const R_xlen_t n = (R_xlen_t)rows * s0 * d;
+    if (!Rf_isReal(embeds) || Rf_xlength(embeds) != n) Rf_error("t3mi: embeds must be a numeric [rows, S0, d] array");
+    float* out = (float*)malloc((size_t)n * sizeof(float));
+    if (!out) Rf_error("t3mi: out of memory");
+    const double* src = REAL(embeds);
+    for (int r = 0; r < rows; r++)
+        for (int t = 0; t < s0; t++)
+            for (int k = 0; k < d; k++)
+                out[((size_t)r * s0 + t) * d + k] = (float)src[r + (R_xlen_t)rows * (t + (R_xlen_t)s0 * k)];
+    return out;
+}
+
+/* .Call("t3mi_r_generate", model, embeds, c(rows, s0, d), config) -> integer vector of 0-indexed
+ * token ids including the stop token if hit -- the return contract of cpp_t3_decode
+ * (src/t3_decode.cpp:420-427). */
+SEXP t3mi_r_generate(SEXP model, SEXP embeds, SEXP dims, SEXP cfg) {
+    t3mi_model* m = get_model(model);
+    if (Rf_length(dims) != 3) Rf_error("t3mi: dims must be c(rows, S0, d)");
+    const int rows = INTEGER(dims)[0], s0 = INTEGER(dims)[1], d = INTEGER(dims)[2];
+    t3mi_params p;
+    fill_params(cfg, &p);
+    float* e = to_row_major(embeds, rows, s0, d);
+    const int cap = p.max_new_tokens > 0 ? p.max_new_tokens : 1;
+    int32_t* out = (int32_t*)malloc((size_t)cap * sizeof(int32_t));
+    int32_t n = 0;
+    int rc = out ? t3mi_generate(m, e, rows, s0, &p, out, cap, &n) : T3MI_ERR_ARG;
+    free(e);
+    if (rc < 0) { /* free C state first, then longjmp (SURVEY §8b "Errors") */
+        free(out);
+        Rf_error("t3mi_generate: %s", t3mi_last_error());
+    }
+    SEXP res = PROTECT(Rf_allocVector(INTSXP, n));
+    for (int i = 0; i < n; i++) INTEGER(res)[i] = (int)out[i];
+    free(out);
+    if (rc == T3MI_WARN_CACHE_FULL) Rf_warning("KV cache full, stopping generation"); /* src/t3_decode.cpp:395 */
+    UNPROTECT(1);
+    return res;
+}
+
+/* .Call("t3mi_r_generate_batch", model, list_of_embeds, matrix dims [n_utt, 3], config) -> list of
+ * integer vectors (the batched front door for tts_chunked, R/tts.R:462-474). */
+SEXP t3mi_r_generate_batch(SEXP model, SEXP embeds_list, SEXP dims, SEXP cfg) {
+    t3mi_model* m = get_model(model);
+    const int n_utt = Rf_length(embeds_list);
+    if (n_utt <= 0 || Rf_length(dims) != 3 * n_utt) Rf_error("t3mi: dims must be an [n_utt, 3] integer matrix");
+    t3mi_params p;
+    fill_params(cfg, &p);
+    const int* dm = INTEGER(dims); /* column-major [n_utt, 3] */
+    const int rows = dm[0], d = dm[2 * n_utt];
+    float** e = (float**)calloc((size_t)n_utt, sizeof(float*));
+    int32_t* s0 = (int32_t*)malloc((size_t)n_utt * sizeof(int32_t));
+    const int cap = p.max_new_tokens > 0 ? p.max_new_tokens : 1;
+    int32_t* out = (int32_t*)malloc((size_t)n_utt * cap * sizeof(int32_t));
+    int32_t* n_out = (int32_t*)calloc((size_t)n_utt, sizeof(int32_t));
+    int rc = T3MI_OK;
+    if (!e || !s0 || !out || !n_out) rc = T3MI_ERR_ARG;
+    for (int u = 0; u < n_utt && rc == T3MI_OK; u++) {
+        if (dm[u] != rows || dm[2 * n_utt + u] != d) { rc = T3MI_ERR_ARG; break; }
+        s0[u] = dm[n_utt + u];
+        e[u] = to_row_major(VECTOR_ELT(embeds_list, u), rows, s0[u], d);
+    }
+    if (rc == T3MI_OK)
+        rc = t3mi_generate_batch(m, n_utt, rows, (const float* const*)e, s0, &p, out, cap, n_out);
+    if (e) for (int u = 0; u < n_utt; u++) free(e[u]);
+    free(e);
+    free(s0);
+    if (rc < 0) {
+        free(out);
+        free(n_out);
+        Rf_error("t3mi_generate_batch: %s", rc == T3MI_ERR_ARG ? "bad arguments" : t3mi_last_error());
+    }
+    SEXP res = PROTECT(Rf_allocVector(VECSXP, n_utt));
+    for (int u = 0; u < n_utt; u++) {
+        SEXP v = PROTECT(Rf_allocVector(INTSXP, n_out[u]));
+        for (int i = 0; i < n_out[u]; i++) INTEGER(v)[i] = (int)out[(size_t)u * cap + i];
+        SET_VECTOR_ELT(res, u, v);
+        UNPROTECT(1);
+    }
+    free(out);
+    free(n_out);
+    UNPROTECT(1);
+    return res;
+}
+
+static const R_CallMethodDef call_methods[] = {
+    {"t3mi_r_open", (DL_FUNC)&t3mi_r_open, 4},
+    {"t3mi_r_close", (DL_FUNC)&t3mi_r_close, 1},
+    {"t3mi_r_generate", (DL_FUNC)&t3mi_r_generate, 4},
+    {"t3mi_r_generate_batch", (DL_FUNC)&t3mi_r_generate_batch, 4},
+    {NULL, NULL, 0}};
+
+/* same registration pattern as the reference's src/init.c:12-15 */
+void R_init_chatterbox(DllInfo* dll) {
+    R_registerRoutines(dll, NULL, call_methods, NULL, NULL);
+    R_useDynamicSymbols(dll, FALSE);
+}
