@@ -21,29 +21,70 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kHeadDim = 64;
 
+// Wave-wide reductions on the DPP / readlane path: 4 row-local DPP steps (~8 cycles each) + 4
+// v_readlane, instead of 6 dependent ds_bpermute round trips through the LDS crossbar (~100 cycles
+// each) -- the reductions sit on the critical path of every latency-bound decode kernel.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
+    v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);   // row_half_mirror
+    v += dpp_f<0x140>(v);   // row_mirror: every lane of a 16-lane row now holds the row sum
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+// sum within each aligned group of 16 lanes (all 16 lanes get the result)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
     return v;
 }
+
+#ifdef T3K_STAMPS
+// diagnostic build: 100 MHz constant clock, comparable across CUs
+#define T3K_STAMP(args, gw, slot)                                                                  \
+    do {                                                                                           \
+        if ((args).stamps != nullptr && (threadIdx.x & 63) == 0 && (gw) < T3K_STAMP_WAVES)         \
+            (args).stamps[(size_t)(gw) * T3K_STAMP_SLOTS + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define T3K_STAMP(args, gw, slot) do { } while (0)
+#endif
 
 // ---- weight element types --------------------------------------------------------------
 struct F32W {
     static constexpr int E = 4;  // elements per 16-byte load
     __device__ static __forceinline__ void load(const void* base, size_t elem_off, float (&o)[4]) {
-        const float4 v = *reinterpret_cast<const float4*>(static_cast<const float*>(base) + elem_off);
+        // read-once weight stream: non-temporal (does not displace the activations / KV in L2)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(static_cast<const float*>(base) + elem_off));
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     }
 };
 struct BF16W {
     static constexpr int E = 8;
     __device__ static __forceinline__ void load(const void* base, size_t elem_off, float (&o)[8]) {
-        const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(base) + elem_off);
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(static_cast<const uint16_t*>(base) + elem_off));
         o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xFFFF0000u);
         o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xFFFF0000u);
         o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xFFFF0000u);
@@ -86,8 +127,8 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
     constexpr int K = KW * KSPLIT;
     static_assert(EPI == EPI_STORE || EPI == EPI_RESID || (ROWS % 2 == 0), "paired epilogues need even ROWS");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;                                          // [R][K], PRO_ATTN only
-    float* part = smem + (PRO == PRO_ATTN ? R * K : 0);        // [NW][ROWS][R] (KSPLIT > 1)
+    float* xs = smem;                                          // [R][K], PRO_NORM / PRO_ATTN
+    float* part = smem + (PRO != PRO_PLAIN ? R * K : 0);       // [NW][max(ROWS,1)][R] scratch
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
     const int grp = wave / KSPLIT, kpart = wave % KSPLIT, ngrp = nw / KSPLIT;
@@ -98,6 +139,93 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
     const int cstride = (int)gridDim.x * ngrp;
     int c = cb + grp;
 
+    [[maybe_unused]] const int gwave = (int)blockIdx.x * nw + wave;
+    T3K_STAMP(a, gwave, 0);
+
+    // ---- 1. small L2-resident operands FIRST.  Vector-memory results return in issue order, so anything
+    // requested after the weight stream only becomes usable once the weights have landed; requested
+    // before it, the norm / softmax-merge math overlaps the HBM flight of the weights.
+    // 1a. epilogue operands that do not depend on the GEMV (cache slot, RoPE row, residual)
+    int e_pos = -1;
+    float e_c = 0.f, e_s = 0.f, e_res = 0.f;
+    {
+        constexpr int HP = ROWS / 2;
+        if (EPI == EPI_ROPE_KV) {
+            if (lane < HP * R) {
+                const int r = lane % R;
+                e_pos = a.rowpos[r];
+                if (c < n_chunks) {
+                    const int per_head = 32 / HP;
+                    const int i = (c % per_head) * HP + lane / R;   // rotate_half pair index 0..31
+                    // rope_cur[r] = cos/sin rows of row r's CURRENT position, staged by the sampler / prefill
+                    // kernel so that this load does not wait for rowpos (cos[i] == cos[i+32]: emb = cat(freqs, freqs))
+                    e_c = a.rope_cur[(size_t)(2 * r) * kHeadDim + i];
+                    e_s = a.rope_cur[(size_t)(2 * r + 1) * kHeadDim + i];
+                }
+            }
+        } else if (EPI == EPI_RESID) {
+            if (lane < ROWS * R && c < n_chunks && (KSPLIT == 1 || kpart == 0)) {
+                const int n = ROWS * c + lane / R;
+                if (n < a.N) e_res = a.resid[(size_t)(lane % R) * a.ldy + n];
+            }
+        }
+    }
+    // 1b. activation rows: this lane's k-slice (PLAIN / NORM, one L2 round trip per wave, no barrier on the
+    // critical path) or the split-softmax partials of the attention kernel (ATTN, merged once per block)
+    float xv[R][NK][E];
+    constexpr int NXJ = (K / 4 + 127) / 128;   // float4 slices per thread per row at >= 128 threads
+    float4 gx[PRO == PRO_NORM ? NXJ : 1], vx[PRO == PRO_NORM ? R : 1][PRO == PRO_NORM ? NXJ : 1];
+    float rs_row[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rs_row[r] = 1.0f;
+    constexpr int SPC = (R <= 2) ? 8 : 4;                        // attention splits merged per pass
+    constexpr int ITEMS = (R * K / 4 + 255) / 256;               // (row, float4) items per thread, 256-thread block
+    float pmv[PRO == PRO_ATTN ? ITEMS : 1][SPC], plv[PRO == PRO_ATTN ? ITEMS : 1][SPC];
+    float4 pav[PRO == PRO_ATTN ? ITEMS : 1][SPC];
+    int a_pos[PRO == PRO_ATTN ? ITEMS : 1];
+    if (PRO == PRO_ATTN) {
+        constexpr int H = K / kHeadDim;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int idx = tid + it * 256;
+            const bool ok = idx < R * (K / 4);
+            const int r = ok ? idx / (K / 4) : 0, k4 = ok ? idx % (K / 4) : 0;
+            const int head = k4 >> 4, dd = (k4 & 15) << 2;
+            a_pos[it] = ok ? a.rowpos[r] : -1;
+            const size_t b = ((size_t)r * H + head) * a.n_split_max;
+#pragma unroll
+            for (int sp = 0; sp < SPC; ++sp) {
+                const int sc = sp < a.n_split_max ? sp : a.n_split_max - 1;   // clamp, masked below
+                pmv[it][sp] = a.pm[b + sc];
+                plv[it][sp] = a.pl[b + sc];
+                pav[it][sp] = *reinterpret_cast<const float4*>(a.pacc + (b + sc) * kHeadDim + dd);
+            }
+        }
+    } else if (PRO == PRO_NORM) {
+        // the block loads x and the norm weight ONCE (each thread a slice) instead of once per wave:
+        // per-wave copies cost more L1 bandwidth than the weight stream itself (12 KiB per wave)
+#pragma unroll
+        for (int j = 0; j < NXJ; ++j) {
+            const int i = (tid + j * nthr) * 4;
+            if (i < K) {
+                gx[j] = *reinterpret_cast<const float4*>(a.ln_w + i);
+#pragma unroll
+                for (int r = 0; r < R; ++r) vx[r][j] = *reinterpret_cast<const float4*>(a.x + (size_t)r * K + i);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < NK; ++q)
+#pragma unroll
+                for (int e4 = 0; e4 < E; e4 += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(a.x + (size_t)r * K + kbase + q * kWave * E + lane * E + e4);
+                    xv[r][q][e4 + 0] = v.x; xv[r][q][e4 + 1] = v.y; xv[r][q][e4 + 2] = v.z; xv[r][q][e4 + 3] = v.w;
+                }
+    }
+
+    // ---- 2. the weight stream: every load of the wave's first chunk, 1 KiB contiguous per instruction
     float w[ROWS][NK][E];
     auto load_chunk = [&](int cc) {
 #pragma unroll
@@ -111,58 +239,94 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
     };
     if (c < n_chunks) load_chunk(c);
 
-    // Epilogue operands that do not depend on the GEMV (cache position, RoPE row, residual) are
-    // requested now, so the tail of the kernel is reduce -> store with no dependent global load.
-    int e_pos = -1;
-    float e_c = 0.f, e_s = 0.f, e_res = 0.f;
-    {
-        constexpr int HP = ROWS / 2;
-        if (EPI == EPI_ROPE_KV) {
-            if (lane < HP * R) {
-                e_pos = a.rowpos[lane % R];
-                if (e_pos >= 0 && c < n_chunks) {
-                    const int per_head = 32 / HP;
-                    const int i = (c % per_head) * HP + lane / R;   // rotate_half pair index 0..31
-                    e_c = a.rope_cos[(size_t)e_pos * kHeadDim + i];  // cos[i] == cos[i+32] (emb = cat(freqs, freqs))
-                    e_s = a.rope_sin[(size_t)e_pos * kHeadDim + i];
+    // ---- 3. prologue math while the weights are in flight
+    if (PRO == PRO_NORM) {
+        static_assert(PRO != PRO_NORM || KSPLIT == 1, "norm prologue needs the whole row in one wave");
+        // xs[r][k] = w_ln[k] * x[r][k]; the per-row scale rsqrt(mean(x^2)+eps) is a scalar and is applied
+        // to the dot products in the epilogue (R/llama.R:65-72 up to fp32 rounding order), so one barrier
+        // suffices and the reduction is off the FMA critical path.
+        float ssq[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) ssq[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NXJ; ++j) {
+            const int i = (tid + j * nthr) * 4;
+            if (i < K) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float4 v = vx[r][j];
+                    ssq[r] = fmaf(v.x, v.x, ssq[r]); ssq[r] = fmaf(v.y, v.y, ssq[r]);
+                    ssq[r] = fmaf(v.z, v.z, ssq[r]); ssq[r] = fmaf(v.w, v.w, ssq[r]);
+                    float4 o;
+                    o.x = __fmul_rn(gx[j].x, v.x); o.y = __fmul_rn(gx[j].y, v.y);
+                    o.z = __fmul_rn(gx[j].z, v.z); o.w = __fmul_rn(gx[j].w, v.w);
+                    *reinterpret_cast<float4*>(xs + r * K + i) = o;
                 }
             }
-        } else if (EPI == EPI_RESID) {
-            if (lane < ROWS * R && c < n_chunks && (KSPLIT == 1 || kpart == 0)) {
-                const int n = ROWS * c + lane / R;
-                if (n < a.N) e_res = a.resid[(size_t)(lane % R) * a.ldy + n];
-            }
         }
-    }
-
-    // ---- prologue: this lane's k-slice of the activation rows.  PLAIN / NORM read straight from
-    // global memory per wave (one L2 round trip, no barrier on the critical path; the redundant norm
-    // per wave is cheaper than a block-wide exchange); ATTN merges the split-softmax partials once
-    // per block through LDS.
-    float xv[R][NK][E];
-    if (PRO == PRO_ATTN) {
-        const int H = K / kHeadDim;
-        for (int idx = tid; idx < R * (K / 4); idx += nthr) {
-            const int r = idx / (K / 4), k4 = idx % (K / 4);
-            const int head = k4 >> 4, dd = (k4 & 15) << 2;
-            const int pos = a.rowpos[r];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float t = wave_sum(ssq[r]);
+            if (lane == 0) part[wave * R + r] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float t = 0.f;
+            for (int ww = 0; ww < nw; ++ww) t += part[ww * R + r];
+            rs_row[r] = 1.0f / sqrtf(t / (float)K + a.eps);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < NK; ++q)
+#pragma unroll
+                for (int e4 = 0; e4 < E; e4 += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(xs + r * K + kbase + q * kWave * E + lane * E + e4);
+                    xv[r][q][e4 + 0] = v.x; xv[r][q][e4 + 1] = v.y; xv[r][q][e4 + 2] = v.z; xv[r][q][e4 + 3] = v.w;
+                }
+    } else if (PRO == PRO_ATTN) {
+        constexpr int H = K / kHeadDim;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int idx = tid + it * 256;
+            const int pos = a_pos[it];
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (pos >= 0) {
                 const int ns = pos / a.keys_per_split + 1;
-                const size_t b = ((size_t)r * H + head) * a.n_split_max;
-                float M = -INFINITY;
-                for (int s = 0; s < ns; ++s) M = fmaxf(M, a.pm[b + s]);
-                float den = 0.f;
-                for (int s = 0; s < ns; ++s) {
-                    const float ws = expf(a.pm[b + s] - M);
-                    den = fmaf(ws, a.pl[b + s], den);
-                    const float4 v = *reinterpret_cast<const float4*>(a.pacc + (b + s) * kHeadDim + dd);
-                    o.x = fmaf(ws, v.x, o.x); o.y = fmaf(ws, v.y, o.y);
-                    o.z = fmaf(ws, v.z, o.z); o.w = fmaf(ws, v.w, o.w);
+                float M = -INFINITY, den = 0.f;
+                for (int s0 = 0; s0 < ns; s0 += SPC) {
+                    if (s0 > 0) {  // long contexts: further passes (the first pass was requested up front)
+                        const int r = idx / (K / 4), k4 = idx % (K / 4);
+                        const size_t b = ((size_t)r * H + (k4 >> 4)) * a.n_split_max;
+#pragma unroll
+                        for (int sp = 0; sp < SPC; ++sp) {
+                            const int sc = s0 + sp < a.n_split_max ? s0 + sp : a.n_split_max - 1;
+                            pmv[it][sp] = a.pm[b + sc];
+                            plv[it][sp] = a.pl[b + sc];
+                            pav[it][sp] = *reinterpret_cast<const float4*>(a.pacc + (b + sc) * kHeadDim + ((k4 & 15) << 2));
+                        }
+                    }
+                    float Mc = M;
+#pragma unroll
+                    for (int sp = 0; sp < SPC; ++sp)
+                        if (s0 + sp < ns) Mc = fmaxf(Mc, pmv[it][sp]);
+                    const float scale = expf(M - Mc);   // 0 on the first pass
+                    o.x *= scale; o.y *= scale; o.z *= scale; o.w *= scale;
+                    den *= scale;
+#pragma unroll
+                    for (int sp = 0; sp < SPC; ++sp)
+                        if (s0 + sp < ns) {
+                            const float ws = expf(pmv[it][sp] - Mc);
+                            den = fmaf(ws, plv[it][sp], den);
+                            o.x = fmaf(ws, pav[it][sp].x, o.x); o.y = fmaf(ws, pav[it][sp].y, o.y);
+                            o.z = fmaf(ws, pav[it][sp].z, o.z); o.w = fmaf(ws, pav[it][sp].w, o.w);
+                        }
+                    M = Mc;
                 }
                 o.x /= den; o.y /= den; o.z /= den; o.w /= den;
             }
-            *reinterpret_cast<float4*>(xs + r * K + k4 * 4) = o;
+            if (idx < R * (K / 4)) *reinterpret_cast<float4*>(xs + (size_t)idx * 4) = o;
         }
         __syncthreads();
 #pragma unroll
@@ -174,43 +338,12 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
                     const float4 v = *reinterpret_cast<const float4*>(xs + r * K + kbase + q * kWave * E + lane * E + e4);
                     xv[r][q][e4 + 0] = v.x; xv[r][q][e4 + 1] = v.y; xv[r][q][e4 + 2] = v.z; xv[r][q][e4 + 3] = v.w;
                 }
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int q = 0; q < NK; ++q)
-#pragma unroll
-                for (int e4 = 0; e4 < E; e4 += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(a.x + (size_t)r * K + kbase + q * kWave * E + lane * E + e4);
-                    xv[r][q][e4 + 0] = v.x; xv[r][q][e4 + 1] = v.y; xv[r][q][e4 + 2] = v.z; xv[r][q][e4 + 3] = v.w;
-                }
-        if (PRO == PRO_NORM) {
-            static_assert(PRO != PRO_NORM || KSPLIT == 1, "norm prologue needs the whole row in one wave");
-            float lw[NK][E];
-#pragma unroll
-            for (int q = 0; q < NK; ++q)
-#pragma unroll
-                for (int e4 = 0; e4 < E; e4 += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(a.ln_w + q * kWave * E + lane * E + e4);
-                    lw[q][e4 + 0] = v.x; lw[q][e4 + 1] = v.y; lw[q][e4 + 2] = v.z; lw[q][e4 + 3] = v.w;
-                }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float ss = 0.f;
-#pragma unroll
-                for (int q = 0; q < NK; ++q)
-#pragma unroll
-                    for (int e = 0; e < E; ++e) ss = fmaf(xv[r][q][e], xv[r][q][e], ss);
-                ss = wave_sum(ss);
-                const float rs = 1.0f / sqrtf(ss / (float)K + a.eps);
-#pragma unroll
-                for (int q = 0; q < NK; ++q)
-#pragma unroll
-                    for (int e = 0; e < E; ++e) xv[r][q][e] = __fmul_rn(lw[q][e], __fmul_rn(xv[r][q][e], rs));
-            }
-        }
     }
 
+#ifdef T3K_STAMPS
+    asm volatile("" :: "v"(xv[0][0][0]));
+    T3K_STAMP(a, gwave, 1);   // activation rows ready
+#endif
     for (; cb < n_chunks; cb += cstride, c += cstride) {
         const bool live = c < n_chunks;
         float acc[ROWS][R];
@@ -225,12 +358,19 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
                     for (int e = 0; e < E; ++e) s = fmaf(w[j][q][e], xv[r][q][e], s);
                 acc[j][r] = s;
             }
+#ifdef T3K_STAMPS
+        asm volatile("" :: "v"(acc[0][0]));
+        T3K_STAMP(a, gwave, 2);   // weights arrived, FMAs done
+#endif
         const int cn = c + cstride;
         if (cn < n_chunks) load_chunk(cn);  // next chunk's loads fly during the reduction
 #pragma unroll
         for (int j = 0; j < ROWS; ++j)
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[j][r] = wave_sum(acc[j][r]);
+            for (int r = 0; r < R; ++r) {
+                acc[j][r] = wave_sum(acc[j][r]);
+                if (PRO == PRO_NORM) acc[j][r] = __fmul_rn(acc[j][r], rs_row[r]);
+            }
 
         if (KSPLIT > 1) {
             __syncthreads();  // previous iteration's readers are done with part[]
@@ -253,6 +393,10 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
                 }
             if (kpart != 0) continue;  // one wave of the group writes
         }
+#ifdef T3K_STAMPS
+        asm volatile("" :: "v"(acc[0][0]));
+        T3K_STAMP(a, gwave, 3);   // reductions done
+#endif
         if (!live) continue;
 
         if (EPI == EPI_STORE || EPI == EPI_RESID) {
@@ -304,8 +448,8 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
                             if (kind < 2) {
                                 // q*cos + rotate_half(q)*sin, each product rounded (R/llama.R:184-185);
                                 // cos/sin rows repeat with period 32, so one (cos, sin) serves both halves
-                                const float cs = first ? e_c : a.rope_cos[(size_t)pos * kHeadDim + i];
-                                const float sn = first ? e_s : a.rope_sin[(size_t)pos * kHeadDim + i];
+                                const float cs = first ? e_c : a.rope_cur[(size_t)(2 * r) * kHeadDim + i];
+                                const float sn = first ? e_s : a.rope_cur[(size_t)(2 * r + 1) * kHeadDim + i];
                                 const float nlo = __fadd_rn(__fmul_rn(lo, cs), __fmul_rn(-hi, sn));
                                 const float nhi = __fadd_rn(__fmul_rn(hi, cs), __fmul_rn(lo, sn));
                                 lo = nlo; hi = nhi;
@@ -322,6 +466,8 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
                     }
         }
     }
+    T3K_STAMP(a, gwave, 4);   // stores issued
+
 }
 
 // ---- single-query attention over the KV cache, split along the keys ---------------------------------
@@ -333,6 +479,10 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
 __global__ __launch_bounds__(256) void attn_split_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float red[16 * kHeadDim + 32];
     const int h = blockIdx.x, r = blockIdx.y, sp = blockIdx.z;
+#ifdef T3K_STAMPS
+    const int gwave = (((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+#endif
+    T3K_STAMP(a, gwave, 0);
     const int pos = a.rowpos[r];
     if (pos < 0) return;
     const int L = pos + 1;
@@ -362,8 +512,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float dot = fmaf(q4.w, kv[u].w, fmaf(q4.z, kv[u].z, fmaf(q4.y, kv[u].y, q4.x * kv[u].x)));
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 16);
+            dot = row16_sum(dot);
             sc[u] = (p0 + g + 16 * u < k1) ? dot * 0.125f : -INFINITY;  // 1/sqrt(64)
             mloc = fmaxf(mloc, sc[u]);
         }
@@ -404,6 +553,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnArgs a) {
         a.pl[pb] = l;
         a.pm[pb] = m_run;
     }
+    T3K_STAMP(a, gwave, 4);
 }
 
 // ---- token-by-token prefill input: x[r] = embeds[r][t - start[r]] ---------------------------
@@ -412,6 +562,11 @@ __global__ __launch_bounds__(256) void prefill_embed_kernel(EmbedArgs a) {
     const int p = a.t - a.start[r];
     if (threadIdx.x == 0) a.rowpos[r] = p >= 0 ? p : -1;
     if (p < 0) return;
+    if (threadIdx.x < 2 * kHeadDim) {   // cos / sin rows of this position for the QKV kernel's RoPE epilogue
+        const int t = threadIdx.x;
+        a.rope_cur[(size_t)r * 2 * kHeadDim + t] =
+            (t < kHeadDim ? a.rope_cos : a.rope_sin)[(size_t)p * kHeadDim + (t & (kHeadDim - 1))];
+    }
     const float* src = a.emb_rows[r] + (size_t)p * a.d;
     for (int i = threadIdx.x; i < a.d; i += blockDim.x) a.x[(size_t)r * a.d + i] = src[i];
 }
@@ -705,6 +860,10 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
         a.done[u] = dn;
     }
     if (tid < a.rpu) a.rowpos[u * a.rpu + tid] = dn ? -1 : pos_next;
+    if (!dn && tid < 2 * kHeadDim) {
+        const float v = (tid < kHeadDim ? a.rope_cos : a.rope_sin)[(size_t)pos_next * kHeadDim + (tid & (kHeadDim - 1))];
+        for (int rr = 0; rr < a.rpu; ++rr) a.rope_cur[((size_t)u * a.rpu + rr) * 2 * kHeadDim + tid] = v;
+    }
     if (!dn) {
         const float* e = a.emb + (size_t)tok * a.d;
         const float* pe = a.pos_emb + (size_t)(step + 1) * a.d;  // Q11: BOS holds row 0
@@ -721,12 +880,14 @@ hipError_t launch_gemv_t(const GemvArgs& a, hipStream_t s) {
     const int n_chunks = (a.N + ROWS - 1) / ROWS;
     // waves per block: aim at one block per CU (256 CUs) with every load of the launch in flight at once
     int nw = a.waves > 0 ? a.waves : 4;
+    if (PRO == PRO_ATTN) nw = 4;   // the merge prologue is written for a 256-thread block
+    if (PRO == PRO_NORM && nw < 2) nw = 2;   // the norm prologue slices x over >= 128 threads
     if (nw % KSPLIT) nw = ((nw + KSPLIT - 1) / KSPLIT) * KSPLIT;
     if (nw > 8) nw = 8;
     const int per_block = nw / KSPLIT;
     int grid = (n_chunks + per_block - 1) / per_block;
     if (grid > 256 * 8) grid = 256 * 8;
-    const size_t lds = ((PRO == PRO_ATTN ? (size_t)R * K : 0) + (size_t)nw * ROWS * R + 32) * sizeof(float);
+    const size_t lds = ((PRO != PRO_PLAIN ? (size_t)R * K : 0) + (size_t)nw * ROWS * R + 32) * sizeof(float);
     auto kfn = gemv_kernel<WT, R, NK, KSPLIT, ROWS, EPI, PRO>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -817,7 +978,7 @@ hipError_t launch_gemv(const GemvArgs& a, int epilogue, int wdtype, hipStream_t 
     if (epilogue == EPI_SWIGLU && (a.N % 8)) return hipErrorInvalidValue;
     if (epilogue == EPI_ROPE_KV) {
         if (a.N != 3 * a.n_heads * kHeadDim || a.rowpos == nullptr || a.kcache == nullptr ||
-            a.vcache == nullptr || a.rope_cos == nullptr || a.rope_sin == nullptr || a.max_len <= 0)
+            a.vcache == nullptr || a.rope_cur == nullptr || a.max_len <= 0)
             return hipErrorInvalidValue;
     }
     return wdtype == 1 ? launch_gemv_w<BF16W>(a, epilogue, s) : launch_gemv_w<F32W>(a, epilogue, s);

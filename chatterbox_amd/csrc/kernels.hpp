@@ -19,6 +19,11 @@ enum Prologue : int {
     PRO_ATTN = 2,   // merge of the split-softmax attention partials
 };
 
+#ifdef T3K_STAMPS
+#define T3K_STAMP_SLOTS 8
+#define T3K_STAMP_WAVES 8192
+#endif
+
 struct GemvArgs {
     const void* W = nullptr;      // [N, K] row-major (row = output feature), fp32 or bf16
     const float* x = nullptr;     // [rows, K]
@@ -31,8 +36,7 @@ struct GemvArgs {
     int ldy = 0;
     // EPI_ROPE_KV
     const int* rowpos = nullptr;  // [rows] cache position of the token in x[r]; < 0 = inactive row
-    const float* rope_cos = nullptr;  // [max_pos, 64]
-    const float* rope_sin = nullptr;
+    const float* rope_cur = nullptr;  // [rows][2][64] cos / sin rows of each row's current position
     float* kcache = nullptr;      // this layer, these rows: [rows][H][max_len][64]
     float* vcache = nullptr;
     int n_heads = 0, max_len = 0;
@@ -43,6 +47,9 @@ struct GemvArgs {
     int n_split_max = 0, keys_per_split = 0;
     int waves = 0;                // waves per block (0 = default 4)
     int rows_per_chunk = 0;       // output features per wave-chunk (0 = kernel default)
+#ifdef T3K_STAMPS
+    unsigned long long* stamps = nullptr;  // diagnostic build only: [T3K_STAMP_WAVES][T3K_STAMP_SLOTS] of this launch
+#endif
 };
 
 struct AttnArgs {
@@ -55,6 +62,9 @@ struct AttnArgs {
     float* pacc = nullptr;
     int rows = 0, n_heads = 0, max_len = 0;
     int n_split_max = 0, keys_per_split = 64;
+#ifdef T3K_STAMPS
+    unsigned long long* stamps = nullptr;
+#endif
 };
 
 struct EmbedArgs {                // token-by-token prefill input (R/t3.R:494, :505)
@@ -64,6 +74,9 @@ struct EmbedArgs {                // token-by-token prefill input (R/t3.R:494, :
     int d = 0, rows = 0;
     float* x = nullptr;           // [rows, d]
     int* rowpos = nullptr;        // [rows] out
+    const float* rope_cos = nullptr;  // [max_len, 64] (R/llama.R:87-112)
+    const float* rope_sin = nullptr;
+    float* rope_cur = nullptr;    // [rows][2][64] out
 };
 
 struct SamplerArgs {
@@ -85,6 +98,9 @@ struct SamplerArgs {
     const float* pos_emb = nullptr;  // speech_pos_emb [max_pos, d]
     int d = 0, max_pos = 0, max_len = 0;
     float* x = nullptr;           // [n_utt*rpu, d] next-token embedding out
+    const float* rope_cos = nullptr;  // [max_len, 64]
+    const float* rope_sin = nullptr;
+    float* rope_cur = nullptr;    // [n_utt*rpu][2][64] out: RoPE rows of the next token's position
     int* dist_ids = nullptr;      // [n_utt, dist_cap] debug (may be nullptr)
     float* dist_probs = nullptr;
     int* dist_n = nullptr;

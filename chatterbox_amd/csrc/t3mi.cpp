@@ -71,7 +71,7 @@ struct Session {
     int kps = 64, n_split = 1;  // attention split: keys per block, blocks per (row, head)
     t3mi_params prm{};
     std::vector<int32_t> s0;
-    DevBuf kc, vc, x, qbuf, pm, pl, pacc, hbuf, logits, rowpos, start, emb_rows, emb_data, seen, tokens, n_tokens,
+    DevBuf kc, vc, x, qbuf, pm, pl, pacc, hbuf, logits, rope_cur, rowpos, start, emb_rows, emb_data, seen, tokens, n_tokens,
         done, s0_dev, forced, dist_ids, dist_probs, dist_n, drawn;
     int n_forced = 0;
     hipGraph_t graph = nullptr;
@@ -98,7 +98,7 @@ struct t3mi_model {
     int64_t weight_bytes = 0;
     std::unique_ptr<Session> sess;
     bool use_graph = true;
-    int tune[5] = {4, 4, 4, 4, 4};  // waves per block: qkv, o_proj, gate_up, down, head (T3MI_WAVES=a,b,c,d,e)
+    int tune[5] = {8, 4, 8, 8, 8};  // waves per block: qkv, o_proj, gate_up, down, head (T3MI_WAVES=a,b,c,d,e)
     int tune_rows[5] = {2, 1, 2, 2, 2};  // output rows per wave-chunk, same order (T3MI_ROWS=a,b,c,d,e)
 };
 
@@ -275,6 +275,18 @@ int load_llama(t3mi_model* m, const t3mi::SafeTensorsFile& st) {
 }
 
 // ---- one transformer pass over the rows currently in sess->x ------------------------------------
+#ifdef T3K_STAMPS
+unsigned long long* g_stamp_buf = nullptr;   // [launch][T3K_STAMP_WAVES][T3K_STAMP_SLOTS]
+int g_stamp_launch = 0;
+unsigned long long* next_stamps() {
+    if (!g_stamp_buf) return nullptr;
+    return g_stamp_buf + (size_t)(g_stamp_launch++) * T3K_STAMP_WAVES * T3K_STAMP_SLOTS;
+}
+#define T3MI_SET_STAMPS(a) (a).stamps = next_stamps()
+#else
+#define T3MI_SET_STAMPS(a) do { } while (0)
+#endif
+
 struct StepTimer {  // optional per-launch events for t3mi_session_profile_step
     std::vector<hipEvent_t> ev;
     std::vector<int> kind;
@@ -308,11 +320,12 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.N = 3 * d; a.K = d; a.rows = rg;
             a.y = s->qbuf.as<float>() + (size_t)r0 * d; a.ldy = d;
             a.rowpos = s->rowpos.as<int>() + r0;
-            a.rope_cos = m->rope_cos.as<float>(); a.rope_sin = m->rope_sin.as<float>();
+            a.rope_cur = s->rope_cur.as<float>() + (size_t)r0 * 128;
             a.kcache = kc + (size_t)r0 * H * s->max_len * 64;
             a.vcache = vc + (size_t)r0 * H * s->max_len * 64;
             a.n_heads = H; a.max_len = s->max_len;
             a.waves = m->tune[0]; a.rows_per_chunk = m->tune_rows[0];
+            T3MI_SET_STAMPS(a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_ROPE_KV, m->wdtype, m->stream));
             r0 += rg;
         }
@@ -324,6 +337,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.pm = s->pm.as<float>(); a.pl = s->pl.as<float>(); a.pacc = s->pacc.as<float>();
             a.rows = s->rows; a.n_heads = H; a.max_len = s->max_len;
             a.n_split_max = s->n_split; a.keys_per_split = s->kps;
+            T3MI_SET_STAMPS(a);
             HIPCHK(t3k::launch_attn_decode(a, m->stream));
         }
         if (tm) tm->mark(K_ATTN);
@@ -339,6 +353,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.rowpos = s->rowpos.as<int>() + r0;
             a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
             a.waves = m->tune[1]; a.rows_per_chunk = m->tune_rows[1];
+            T3MI_SET_STAMPS(a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
             r0 += rg;
         }
@@ -351,6 +366,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.N = 2 * F; a.K = d; a.rows = rg;
             a.y = s->hbuf.as<float>() + (size_t)r0 * F; a.ldy = F;
             a.waves = m->tune[2]; a.rows_per_chunk = m->tune_rows[2];
+            T3MI_SET_STAMPS(a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_SWIGLU, m->wdtype, m->stream));
             r0 += rg;
         }
@@ -362,6 +378,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.W = lw.wdown; a.x = s->hbuf.as<float>() + (size_t)r0 * F; a.N = d; a.K = F; a.rows = rg;
             a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
             a.waves = m->tune[3]; a.rows_per_chunk = m->tune_rows[3];
+            T3MI_SET_STAMPS(a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
             r0 += rg;
         }
@@ -379,6 +396,7 @@ int run_head(t3mi_model* m, Session* s, StepTimer* tm) {
         a.N = m->V; a.K = d; a.rows = rg;
         a.y = s->logits.as<float>() + (size_t)r0 * m->V; a.ldy = m->V;
         a.waves = m->tune[4]; a.rows_per_chunk = m->tune_rows[4];
+        T3MI_SET_STAMPS(a);
         HIPCHK(t3k::launch_gemv(a, t3k::EPI_STORE, m->wdtype, m->stream));
         r0 += rg;
     }
@@ -399,6 +417,7 @@ int run_sampler(t3mi_model* m, Session* s, StepTimer* tm) {
     a.forced = s->n_forced > 0 ? s->forced.as<int>() : nullptr; a.n_forced = s->n_forced;
     a.emb = m->emb.as<float>(); a.pos_emb = m->pos_emb.as<float>(); a.d = m->d; a.max_pos = m->max_pos;
     a.max_len = s->max_len; a.x = s->x.as<float>();
+    a.rope_cos = m->rope_cos.as<float>(); a.rope_sin = m->rope_sin.as<float>(); a.rope_cur = s->rope_cur.as<float>();
     a.dist_ids = s->dist_ids.as<int>(); a.dist_probs = s->dist_probs.as<float>(); a.dist_n = s->dist_n.as<int>();
     a.drawn = s->drawn.as<int>();
     a.dist_cap = m->V;
@@ -605,6 +624,8 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     HIPCHK(s->hbuf.alloc(rows * F * 4));
     HIPCHK(s->logits.alloc(rows * V * 4));
     HIPCHK(s->rowpos.alloc(rows * 4));
+    HIPCHK(s->rope_cur.alloc(rows * 128 * 4));
+    HIPCHK(hipMemsetAsync(s->rope_cur.p, 0, rows * 128 * 4, m->stream));
     HIPCHK(s->start.alloc(rows * 4));
     HIPCHK(s->emb_rows.alloc(rows * sizeof(void*)));
     HIPCHK(s->seen.alloc(U * V));
@@ -677,6 +698,7 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         e.start = s->start.as<int>();
         e.t = t; e.d = m->d; e.rows = s->rows;
         e.x = s->x.as<float>(); e.rowpos = s->rowpos.as<int>();
+        e.rope_cos = m->rope_cos.as<float>(); e.rope_sin = m->rope_sin.as<float>(); e.rope_cur = s->rope_cur.as<float>();
         HIPCHK(t3k::launch_prefill_embed(e, st));
         if ((rc = run_layers(m, s.get(), nullptr))) return rc;
     }
@@ -861,6 +883,32 @@ int t3mi_session_profile_step(t3mi_model* m, t3mi_kstat* stats, int cap, int* n_
     for (hipEvent_t e : tm.ev) (void)hipEventDestroy(e);
     return rc;
 }
+
+#ifdef T3K_STAMPS
+// diagnostic build only: run ONE eager decode step with per-wave timestamps; out receives
+// [n_launches][T3K_STAMP_WAVES][T3K_STAMP_SLOTS] u64 (100 MHz ticks); returns n_launches or < 0
+int t3mi_debug_stamp_step(t3mi_model* m, unsigned long long* out, int max_launches) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    Session* s = m->sess.get();
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    const size_t per = (size_t)T3K_STAMP_WAVES * T3K_STAMP_SLOTS;
+    DevBuf buf;
+    HIPCHK(buf.alloc((size_t)max_launches * per * 8));
+    HIPCHK(hipMemset(buf.p, 0, (size_t)max_launches * per * 8));
+    g_stamp_buf = buf.as<unsigned long long>();
+    g_stamp_launch = 0;
+    rc = run_decode_step(m, s, nullptr);
+    g_stamp_buf = nullptr;
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    const int n = g_stamp_launch;
+    if (n > max_launches) return fail(T3MI_ERR_ARG, "stamp buffer too small");
+    HIPCHK(hipMemcpy(out, buf.p, (size_t)n * per * 8, hipMemcpyDeviceToHost));
+    return n;
+}
+#endif
 
 int t3mi_generate_batch(t3mi_model* m, int n_utt, int rpu, const float* const* embeds, const int32_t* s0,
                         const t3mi_params* p, int32_t* out, int32_t cap, int32_t* n_out) {

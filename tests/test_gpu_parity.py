@@ -165,3 +165,42 @@ def test_full_size_model_logits_and_greedy_tokens():
             assert list(s.tokens(0)) == ref.tokens
     finally:
         model.close()
+
+
+BF16_LOGIT_TOL = 3e-2   # bf16 weight storage (8 significant bits), fp32 activations / accumulate
+
+
+def _bf16_round(a: np.ndarray) -> np.ndarray:
+    u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def test_tiny_bf16_weights_match_oracle_on_rounded_weights():
+    """bf16 tolerance is stated separately (BASELINE.json): with the oracle run on the SAME
+    bf16-rounded matrices the fp32 bar (1e-3) holds; against the fp32 oracle the error is the
+    quantisation error of the weights (<= 3e-2 of max|logit| on this model)."""
+    dims = synth.TINY
+    path = synth.ensure_checkpoint(dims, 1234)
+    w = synth.synth_llama_weights(dims, 1234)
+    wq = {k: (_bf16_round(v) if (v.ndim == 2 and "emb" not in k) else v) for k, v in w.items()}
+    from tests.helpers import oracle_cfg
+    om_q = O.LlamaOracle(wq, oracle_cfg(dims))
+    om = O.LlamaOracle(w, oracle_cfg(dims))
+    emb = synth.synth_embeds(2, 10, dims.hidden_size, 5)
+    n = 12
+    ref_q = O.t3_inference(om_q, emb, O.SampleParams(max_new_tokens=n, top_p=0.0), mask_stop=True)
+    ref = O.t3_inference(om, emb, O.SampleParams(max_new_tokens=n, top_p=0.0), mask_stop=True,
+                         forced_tokens=ref_q.tokens)
+    model = cb.load_t3(path, device=0, dtype="bf16", start_speech_token=dims.start_speech_token,
+                       stop_speech_token=dims.stop_speech_token)
+    try:
+        with cb.Session(model, [emb], max_new_tokens=n, top_p=0.0, mask_stop=True) as s:
+            for i in range(n):
+                lg = s.logits()
+                assert rel_err(lg, ref_q.raw_logits[i]) < LOGIT_TOL, f"step {i} (rounded-weight oracle)"
+                assert rel_err(lg, ref.raw_logits[i]) < BF16_LOGIT_TOL, f"step {i} (fp32 oracle)"
+                s.decode(1)
+            assert list(s.tokens(0)) == ref_q.tokens
+    finally:
+        model.close()
