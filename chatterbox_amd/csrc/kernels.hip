@@ -491,7 +491,8 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnArgs a) {
     const int k1 = min(L, k0 + a.keys_per_split);
     const int tid = threadIdx.x, g = tid >> 4, sub = tid & 15, wave = tid >> 6;
     const int d = a.n_heads * kHeadDim;
-    const size_t base = ((size_t)r * a.n_heads + h) * a.max_len * kHeadDim;
+    const int crow = a.rowmap ? a.rowmap[r] : r;
+    const size_t base = ((size_t)crow * a.n_heads + h) * a.max_len * kHeadDim;
     const float* Kp = a.kcache + base;
     const float* Vp = a.vcache + base;
     const float4 q4 = *reinterpret_cast<const float4*>(a.q + (size_t)r * d + h * kHeadDim + sub * 4);

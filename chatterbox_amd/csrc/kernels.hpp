@@ -56,7 +56,8 @@ struct AttnArgs {
     const float* q = nullptr;     // [rows, H*64] (RoPE applied)
     const float* kcache = nullptr;  // [rows][H][max_len][64]
     const float* vcache = nullptr;
-    const int* rowpos = nullptr;  // [rows]; attends to positions 0..rowpos[r]
+    const int* rowpos = nullptr;  // [rows]; query r attends to positions 0..rowpos[r] (< 0 = inactive)
+    const int* rowmap = nullptr;  // [rows] cache row of query r (nullptr = identity; prefill: many queries per row)
     float* pm = nullptr;          // partial outputs, see GemvArgs
     float* pl = nullptr;
     float* pacc = nullptr;
@@ -65,6 +66,26 @@ struct AttnArgs {
 #ifdef T3K_STAMPS
     unsigned long long* stamps = nullptr;
 #endif
+};
+
+// many-row regime (batched decode, prefill): skinny GEMM on the matrix cores, see batch_kernels.hip
+struct GemmArgs {
+    const void* W = nullptr;      // [N, K] row-major, fp32 or bf16
+    const void* A = nullptr;      // [M, K] activation rows: float (fp32 weights) or bf16 (bf16 weights)
+    int M = 0, N = 0, K = 0;
+    float* y = nullptr;           // EPI_STORE / EPI_RESID output [M, ldy] fp32
+    const float* resid = nullptr; // may alias y
+    int ldy = 0;
+    void* yact = nullptr;         // EPI_SWIGLU output [M, N/2] in the activation type
+    // EPI_ROPE_KV
+    const int* posmap = nullptr;  // [M] cache slot of item m (< 0 = inactive)
+    const int* rowmap = nullptr;  // [M] cache row of item m (nullptr = identity)
+    const float* rope_cos = nullptr;  // [max_len, 64]
+    const float* rope_sin = nullptr;
+    float* q = nullptr;           // [M, H*64] fp32
+    float* kcache = nullptr;      // this layer: [cache rows][H][max_len][64]
+    float* vcache = nullptr;
+    int n_heads = 0, max_len = 0;
 };
 
 struct EmbedArgs {                // token-by-token prefill input (R/t3.R:494, :505)
@@ -117,6 +138,12 @@ hipError_t launch_gemv(const GemvArgs& a, int epilogue, int wdtype, hipStream_t 
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t s);
 hipError_t launch_prefill_embed(const EmbedArgs& a, hipStream_t s);
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t s);
+hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t s);
+hipError_t launch_rmsnorm_rows(const float* x, const float* w, float eps, void* out, int M, int d, int act_bf16,
+                               hipStream_t s);
+hipError_t launch_attn_merge(const float* pm, const float* pl, const float* pacc, const int* posmap, void* out, int M,
+                             int H, int n_split_max, int kps, int act_bf16, hipStream_t s);
+hipError_t launch_gather_rows(const float* const* src_rows, float* x, int M, int d, hipStream_t s);
 // fp32 -> bf16 (round to nearest even) on device, n elements
 hipError_t launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 

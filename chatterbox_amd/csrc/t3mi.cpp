@@ -69,6 +69,8 @@ struct LayerW {
 struct Session {
     int n_utt = 0, rpu = 1, rows = 0, max_len = 0, cap = 0, max_s0 = 0;
     int kps = 64, n_split = 1;  // attention split: keys per block, blocks per (row, head)
+    bool gemm_mode = false;     // > 4 activation rows: linears run as MFMA GEMMs (batch_kernels.hip)
+    DevBuf xn, attn_out, hact;  // GEMM-path activation rows (float with fp32 weights, bf16 with bf16 weights)
     t3mi_params prm{};
     std::vector<int32_t> s0;
     DevBuf kc, vc, x, qbuf, pm, pl, pacc, hbuf, logits, rope_cur, rowpos, start, emb_rows, emb_data, seen, tokens, n_tokens,
@@ -387,8 +389,97 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
     return T3MI_OK;
 }
 
+// ---- many-row path: the same layer as MFMA GEMMs over M items (batched decode rows, or the flat list of
+// (row, position) prompt items of a prefill).  posmap[m] = cache slot, rowmap[m] = cache row (nullptr = m).
+struct GemmCtx {
+    int M = 0;
+    float* x = nullptr;        // [M][d] residual stream
+    float* q = nullptr;        // [M][d]
+    void* xn = nullptr;        // [M][d] activation type
+    void* attn_out = nullptr;  // [M][d]
+    void* hact = nullptr;      // [M][F]
+    const int* posmap = nullptr;
+    const int* rowmap = nullptr;
+    float *pm = nullptr, *pl = nullptr, *pacc = nullptr;
+    int kps = 64, n_split = 1;
+};
+
+int run_layers_gemm(t3mi_model* m, Session* s, const GemmCtx& c, StepTimer* tm) {
+    const int d = m->d, F = m->F, H = m->H;
+    const int abf = m->wdtype == T3MI_W_BF16 ? 1 : 0;
+    const size_t layer_kv = (size_t)s->rows * H * s->max_len * 64;
+    hipStream_t st = m->stream;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const LayerW& lw = m->layers[l];
+        float* kc = s->kc.as<float>() + layer_kv * l;
+        float* vc = s->vc.as<float>() + layer_kv * l;
+        HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln1, m->eps, c.xn, c.M, d, abf, st));
+        {
+            t3k::GemmArgs a;
+            a.W = lw.wqkv; a.A = c.xn; a.M = c.M; a.N = 3 * d; a.K = d;
+            a.posmap = c.posmap; a.rowmap = c.rowmap;
+            a.rope_cos = m->rope_cos.as<float>(); a.rope_sin = m->rope_sin.as<float>();
+            a.q = c.q; a.kcache = kc; a.vcache = vc; a.n_heads = H; a.max_len = s->max_len;
+            HIPCHK(t3k::launch_gemm(a, t3k::EPI_ROPE_KV, m->wdtype, st));
+        }
+        if (tm) tm->mark(K_QKV);
+        {
+            t3k::AttnArgs a;
+            a.q = c.q; a.kcache = kc; a.vcache = vc; a.rowpos = c.posmap; a.rowmap = c.rowmap;
+            a.pm = c.pm; a.pl = c.pl; a.pacc = c.pacc;
+            a.rows = c.M; a.n_heads = H; a.max_len = s->max_len;
+            a.n_split_max = c.n_split; a.keys_per_split = c.kps;
+            HIPCHK(t3k::launch_attn_decode(a, st));
+        }
+        if (tm) tm->mark(K_ATTN);
+        HIPCHK(t3k::launch_attn_merge(c.pm, c.pl, c.pacc, c.posmap, c.attn_out, c.M, H, c.n_split, c.kps, abf, st));
+        {
+            t3k::GemmArgs a;
+            a.W = lw.wo; a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
+            a.y = c.x; a.resid = c.x; a.ldy = d;
+            HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, m->wdtype, st));
+        }
+        if (tm) tm->mark(K_OPROJ);
+        HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln2, m->eps, c.xn, c.M, d, abf, st));
+        {
+            t3k::GemmArgs a;
+            a.W = lw.wgu; a.A = c.xn; a.M = c.M; a.N = 2 * F; a.K = d; a.yact = c.hact;
+            HIPCHK(t3k::launch_gemm(a, t3k::EPI_SWIGLU, m->wdtype, st));
+        }
+        if (tm) tm->mark(K_GATEUP);
+        {
+            t3k::GemmArgs a;
+            a.W = lw.wdown; a.A = c.hact; a.M = c.M; a.N = d; a.K = F;
+            a.y = c.x; a.resid = c.x; a.ldy = d;
+            HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, m->wdtype, st));
+        }
+        if (tm) tm->mark(K_DOWN);
+    }
+    return T3MI_OK;
+}
+
+GemmCtx decode_ctx(Session* s) {
+    GemmCtx c;
+    c.M = s->rows; c.x = s->x.as<float>(); c.q = s->qbuf.as<float>();
+    c.xn = s->xn.p; c.attn_out = s->attn_out.p; c.hact = s->hact.p;
+    c.posmap = s->rowpos.as<int>(); c.rowmap = nullptr;
+    c.pm = s->pm.as<float>(); c.pl = s->pl.as<float>(); c.pacc = s->pacc.as<float>();
+    c.kps = s->kps; c.n_split = s->n_split;
+    return c;
+}
+
 int run_head(t3mi_model* m, Session* s, StepTimer* tm) {
     const int d = m->d;
+    if (s->gemm_mode) {
+        const int abf = m->wdtype == T3MI_W_BF16 ? 1 : 0;
+        HIPCHK(t3k::launch_rmsnorm_rows(s->x.as<float>(), m->norm_w, m->eps, s->xn.p, s->rows, d, abf, m->stream));
+        t3k::GemmArgs a;
+        a.W = m->head_w; a.A = s->xn.p; a.M = s->rows; a.N = m->V; a.K = d;
+        a.y = s->logits.as<float>(); a.ldy = m->V;
+        HIPCHK(t3k::launch_gemm(a, t3k::EPI_STORE, m->wdtype, m->stream));
+        if (tm) tm->mark(K_HEAD);
+        return T3MI_OK;
+    }
     for (int r0 = 0; r0 < s->rows;) {
         const int rem = s->rows - r0, rg = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
         t3k::GemvArgs a;
@@ -429,7 +520,9 @@ int run_sampler(t3mi_model* m, Session* s, StepTimer* tm) {
 int run_decode_step(t3mi_model* m, Session* s, StepTimer* tm) {
     int rc;
     if ((rc = run_sampler(m, s, tm))) return rc;
-    if ((rc = run_layers(m, s, tm))) return rc;
+    if (s->gemm_mode) rc = run_layers_gemm(m, s, decode_ctx(s), tm);
+    else rc = run_layers(m, s, tm);
+    if (rc) return rc;
     return run_head(m, s, tm);
 }
 
@@ -622,6 +715,15 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     HIPCHK(s->pl.alloc(rows * m->H * (size_t)s->n_split * 4));
     HIPCHK(s->pacc.alloc(rows * m->H * (size_t)s->n_split * 64 * 4));
     HIPCHK(s->hbuf.alloc(rows * F * 4));
+    {
+        const char* gm = std::getenv("T3MI_GEMM_ROWS");  // rows above which the MFMA path is used (default 4)
+        const int thr = gm ? std::atoi(gm) : 4;
+        s->gemm_mode = (int)rows > thr;
+        const size_t as = m->wdtype == T3MI_W_BF16 ? 2 : 4;
+        HIPCHK(s->xn.alloc(rows * d * as));
+        HIPCHK(s->attn_out.alloc(rows * d * as));
+        HIPCHK(s->hact.alloc(rows * F * as));
+    }
     HIPCHK(s->logits.alloc(rows * V * 4));
     HIPCHK(s->rowpos.alloc(rows * 4));
     HIPCHK(s->rope_cur.alloc(rows * 128 * 4));
@@ -691,16 +793,73 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     }
     HIPCHK(hipStreamSynchronize(st));  // row_ptr/start are stack-local
 
-    // prefill, one prompt position per pass (decode kernels; the batched prefill GEMM is a later row)
-    for (int t = 0; t < max_s0; ++t) {
-        t3k::EmbedArgs e;
-        e.emb_rows = s->emb_rows.as<const float*>();
-        e.start = s->start.as<int>();
-        e.t = t; e.d = m->d; e.rows = s->rows;
-        e.x = s->x.as<float>(); e.rowpos = s->rowpos.as<int>();
-        e.rope_cos = m->rope_cos.as<float>(); e.rope_sin = m->rope_sin.as<float>(); e.rope_cur = s->rope_cur.as<float>();
-        HIPCHK(t3k::launch_prefill_embed(e, st));
-        if ((rc = run_layers(m, s.get(), nullptr))) return rc;
+    // ---- prefill (R/t3.R:505): all prompt positions of all rows as ONE list of (row, position) items through
+    // the MFMA GEMM path (causality = each item attends to cache slots <= its own position; Q12's -65504
+    // mask contributes exactly 0 in fp32).  bf16 weights with <= 4 rows keep fp32 activations and run the
+    // decode kernels one position at a time instead (T3MI_PREFILL=token forces that path).
+    const char* pfenv = std::getenv("T3MI_PREFILL");
+    bool gemm_prefill = (m->wdtype == T3MI_W_F32) || s->gemm_mode;
+    if (pfenv && std::strcmp(pfenv, "token") == 0) gemm_prefill = false;
+    if (pfenv && std::strcmp(pfenv, "gemm") == 0) gemm_prefill = true;
+    if (gemm_prefill) {
+        size_t items = 0;
+        for (int u = 0; u < n_utt; ++u) items += (size_t)rpu * s0[u];
+        std::vector<const float*> isrc(items);
+        std::vector<int32_t> ipos(items), irow(items);
+        std::vector<const float*> last(rows);
+        size_t it = 0;
+        DevBuf xpf, qpf, xnpf, aopf, hpf, ppm, ppl, ppacc, dsrc, dpos, drow, dlast;
+        const size_t as = m->wdtype == T3MI_W_BF16 ? 2 : 4;
+        HIPCHK(xpf.alloc(items * d * 4));
+        for (int r = 0; r < (int)rows; ++r) {
+            const int u = r / rpu;
+            for (int t = 0; t < s0[u]; ++t, ++it) {
+                isrc[it] = row_ptr[r] + (size_t)t * d;
+                ipos[it] = t;
+                irow[it] = r;
+            }
+            last[r] = xpf.as<float>() + (it - 1) * d;
+        }
+        const int kps_pf = 256;
+        const int nsp_pf = (s->max_len + kps_pf - 1) / kps_pf;
+        HIPCHK(qpf.alloc(items * d * 4));
+        HIPCHK(xnpf.alloc(items * d * as));
+        HIPCHK(aopf.alloc(items * d * as));
+        HIPCHK(hpf.alloc(items * F * as));
+        HIPCHK(ppm.alloc(items * m->H * (size_t)nsp_pf * 4));
+        HIPCHK(ppl.alloc(items * m->H * (size_t)nsp_pf * 4));
+        HIPCHK(ppacc.alloc(items * m->H * (size_t)nsp_pf * 64 * 4));
+        HIPCHK(dsrc.alloc(items * sizeof(void*)));
+        HIPCHK(dpos.alloc(items * 4));
+        HIPCHK(drow.alloc(items * 4));
+        HIPCHK(dlast.alloc(rows * sizeof(void*)));
+        HIPCHK(hipMemcpyAsync(dsrc.p, isrc.data(), items * sizeof(void*), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dpos.p, ipos.data(), items * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(drow.p, irow.data(), items * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dlast.p, last.data(), rows * sizeof(void*), hipMemcpyHostToDevice, st));
+        HIPCHK(t3k::launch_gather_rows(dsrc.as<const float*>(), xpf.as<float>(), (int)items, m->d, st));
+        GemmCtx c;
+        c.M = (int)items; c.x = xpf.as<float>(); c.q = qpf.as<float>();
+        c.xn = xnpf.p; c.attn_out = aopf.p; c.hact = hpf.p;
+        c.posmap = dpos.as<int>(); c.rowmap = drow.as<int>();
+        c.pm = ppm.as<float>(); c.pl = ppl.as<float>(); c.pacc = ppacc.as<float>();
+        c.kps = kps_pf; c.n_split = nsp_pf;
+        if ((rc = run_layers_gemm(m, s.get(), c, nullptr))) return rc;
+        // the last prompt position of every row feeds the first speech-head evaluation
+        HIPCHK(t3k::launch_gather_rows(dlast.as<const float*>(), s->x.as<float>(), (int)rows, m->d, st));
+        HIPCHK(hipStreamSynchronize(st));  // host vectors and the prefill scratch die here
+    } else {
+        for (int t = 0; t < max_s0; ++t) {
+            t3k::EmbedArgs e;
+            e.emb_rows = s->emb_rows.as<const float*>();
+            e.start = s->start.as<int>();
+            e.t = t; e.d = m->d; e.rows = s->rows;
+            e.x = s->x.as<float>(); e.rowpos = s->rowpos.as<int>();
+            e.rope_cos = m->rope_cos.as<float>(); e.rope_sin = m->rope_sin.as<float>(); e.rope_cur = s->rope_cur.as<float>();
+            HIPCHK(t3k::launch_prefill_embed(e, st));
+            // (the one-position path always uses the decode GEMV kernels, whatever the row count)
+            if ((rc = run_layers(m, s.get(), nullptr))) return rc;
+        }
     }
     if ((rc = run_head(m, s.get(), nullptr))) return rc;
     HIPCHK(hipStreamSynchronize(st));

@@ -204,3 +204,34 @@ def test_tiny_bf16_weights_match_oracle_on_rounded_weights():
             assert list(s.tokens(0)) == ref_q.tokens
     finally:
         model.close()
+
+
+def test_tiny_batch16_rows_mfma_path_matches_oracle(tiny):
+    """> 4 activation rows: linears run as fp32 MFMA GEMMs (exact fp32 fma chains); ragged prompts."""
+    dims, model, om = tiny
+    lens = [7, 21, 12, 9, 30, 5, 16, 11]
+    embs = [synth.synth_embeds(2, L, dims.hidden_size, 300 + i) for i, L in enumerate(lens)]
+    n = 10
+    with cb.Session(model, embs, max_new_tokens=n, top_p=0.0, mask_stop=True) as s:
+        lg0 = s.logits()
+        s.decode(n)
+        outs = [s.tokens(u) for u in range(len(embs))]
+    for u, e in enumerate(embs):
+        ref = O.t3_inference(om, e, O.SampleParams(max_new_tokens=n, top_p=0.0), mask_stop=True)
+        assert rel_err(lg0[2 * u:2 * u + 2], ref.raw_logits[0]) < LOGIT_TOL, f"utt {u} prefill logits"
+        assert list(outs[u]) == ref.tokens, f"utt {u}"
+
+
+def test_prefill_paths_agree(tiny, monkeypatch):
+    """The batched MFMA prefill and the one-position-at-a-time prefill give the same first logits."""
+    dims, model, om = tiny
+    emb = synth.synth_embeds(2, 23, dims.hidden_size, 71)
+    res = {}
+    for mode in ("gemm", "token"):
+        monkeypatch.setenv("T3MI_PREFILL", mode)
+        with cb.Session(model, [emb], max_new_tokens=4, top_p=0.0, mask_stop=True) as s:
+            res[mode] = s.logits()
+    monkeypatch.delenv("T3MI_PREFILL")
+    assert rel_err(res["gemm"], res["token"]) < 1e-5
+    ref = O.t3_inference(om, emb, O.SampleParams(max_new_tokens=1, top_p=0.0), mask_stop=True)
+    assert rel_err(res["gemm"], ref.raw_logits[0]) < LOGIT_TOL
