@@ -79,18 +79,18 @@ __device__ __forceinline__ int tile_feature(int t, int n, int N) {
     return 16 * t + n;
 }
 
-template <typename G, int MT, int EPI>
-__global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs a) {
+template <typename G, int MT, int KS, int EPI>
+__global__ __launch_bounds__(KS * 64) void mfma_gemm_kernel(GemmArgs a) {
     using AT = typename G::AT;
     constexpr int KB = G::KB;
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][MT*16][16]
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [KS][MT*16][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = lane & 15, g = lane >> 4;
     const int tile = blockIdx.x;
-    const int m0 = blockIdx.y * 128;
+    const int m0 = blockIdx.y * (MT * 16);
     const int Mc = min(a.M - m0, MT * 16);  // rows of this chunk
     const int K = a.K;
-    const int kw = K >> 2;                  // k range of this wave
+    const int kw = K / KS;                  // k range of this wave
     const int kbeg = wave * kw;
     const int per_lane = KB / 4;            // elements per lane per k-block
 
@@ -108,25 +108,34 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // two register stages of UN k-blocks each: the loads of stage s+1 (weights from HBM, activation rows from
+    // L2) are in flight while the MFMAs of stage s run -- a k-block is otherwise one exposed L2 round trip
     const int nkb = kw / KB;
-    constexpr int UN = 4;  // k-blocks in flight
-    for (int j0 = 0; j0 < nkb; j0 += UN) {
-        typename G::Frag bf[UN];
+    constexpr int UN = (MT >= 8) ? 2 : 4;
+    typename G::Frag b0[UN], a0[UN][MT], b1[UN], a1[UN][MT];
+    auto load_stage = [&](int j0, typename G::Frag (&bs)[UN], typename G::Frag (&as)[UN][MT]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int j = (j0 + u < nkb) ? j0 + u : nkb - 1;
-            bf[u] = G::load(a.W, wbase + (size_t)j * KB);
-        }
+            bs[u] = G::load(a.W, wbase + (size_t)j * KB);
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
+            for (int mt = 0; mt < MT; ++mt) as[u][mt] = G::load(a.A, abase[mt] + (size_t)j * KB);
+        }
+    };
+    auto compute_stage = [&](int j0, typename G::Frag (&bs)[UN], typename G::Frag (&as)[UN][MT]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
             if (j0 + u < nkb) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const typename G::Frag af = G::load(a.A, abase[mt] + (size_t)(j0 + u) * KB);
-                    acc[mt] = G::mma(af, bf[u], acc[mt]);
-                }
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = G::mma(as[u][mt], bs[u], acc[mt]);
             }
-        }
+    };
+    load_stage(0, b0, a0);
+    for (int j0 = 0; j0 < nkb; j0 += 2 * UN) {
+        if (j0 + UN < nkb) load_stage(j0 + UN, b1, a1);
+        compute_stage(j0, b0, a0);
+        if (j0 + 2 * UN < nkb) load_stage(j0 + 2 * UN, b0, a0);
+        compute_stage(j0 + UN, b1, a1);
     }
     // K-partials -> LDS: C layout col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
@@ -136,10 +145,13 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs a) {
     __syncthreads();
     auto total = [&](int m, int n) {
         const int o = m * 16 + n;
-        return ((red[o] + red[MT * 256 + o]) + red[2 * MT * 256 + o]) + red[3 * MT * 256 + o];
+        float t = red[o];
+#pragma unroll
+        for (int w2 = 1; w2 < KS; ++w2) t += red[w2 * MT * 256 + o];
+        return t;
     };
     if (EPI == EPI_STORE || EPI == EPI_RESID) {
-        for (int it = tid; it < Mc * 16; it += 256) {
+        for (int it = tid; it < Mc * 16; it += KS * 64) {
             const int m = it >> 4, n = it & 15;
             const int ff = 16 * tile + n;
             if (ff < a.N) {
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs a) {
         }
     } else if (EPI == EPI_SWIGLU) {
         const int F = a.N >> 1;
-        for (int it = tid; it < Mc * 8; it += 256) {
+        for (int it = tid; it < Mc * 8; it += KS * 64) {
             const int m = it >> 3, p = it & 7;
             const float gte = total(m, p), up = total(m, p + 8);
             const float sg = 1.0f / (1.0f + expf(-gte));
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs a) {
         const int hm = tile >> 2, i0 = (tile & 3) << 3;
         const int kind = hm / H, head = hm % H;
         const int d = H * kHeadDim;
-        for (int it = tid; it < Mc * 8; it += 256) {
+        for (int it = tid; it < Mc * 8; it += KS * 64) {
             const int m = it >> 3, p = it & 7;
             const int mi = m0 + m;
             const int pos = a.posmap[mi];
@@ -241,20 +253,36 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* const* __
     for (int i = threadIdx.x; i < d; i += 256) x[(size_t)m * d + i] = s[i];
 }
 
+template <typename G, int MT, int KS, int EPI>
+hipError_t launch_gemm_k(const GemmArgs& a, int tiles, hipStream_t s) {
+    const int chunks = (a.M + MT * 16 - 1) / (MT * 16);
+    const size_t lds = (size_t)KS * MT * 256 * sizeof(float);
+    auto kfn = mfma_gemm_kernel<G, MT, KS, EPI>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3(tiles, chunks), dim3(KS * 64), lds, s, a);
+    return hipGetLastError();
+}
+
 template <typename G, int EPI>
 hipError_t launch_gemm_mt(const GemmArgs& a, int tiles, hipStream_t s) {
-    const int chunks = (a.M + 127) / 128;
-    const int mrows = a.M < 128 ? a.M : 128;
-    const int mt = mrows <= 16 ? 1 : (mrows <= 32 ? 2 : (mrows <= 64 ? 4 : 8));
-    const size_t lds = (size_t)4 * mt * 256 * sizeof(float);
-    dim3 grid(tiles, chunks);
+    // rows per block (MT*16): as many as possible (each block streams its 16 weight rows once) while the
+    // launch still has >= ~256 blocks; K is split over 8 waves when it is long enough
+    int mt = 8;
+    while (mt > 1 && (a.M <= (mt / 2) * 16 || (long long)tiles * ((a.M + mt * 16 - 1) / (mt * 16)) < 256)) mt >>= 1;
+    const bool ks8 = (a.K % (8 * G::KB) == 0) && a.K >= 2048;
+#define T3K_GEMM_CASE(MTV)                                                          \
+    case MTV:                                                                       \
+        return ks8 ? launch_gemm_k<G, MTV, 8, EPI>(a, tiles, s) : launch_gemm_k<G, MTV, 4, EPI>(a, tiles, s);
     switch (mt) {
-        case 1: hipLaunchKernelGGL((mfma_gemm_kernel<G, 1, EPI>), grid, dim3(256), lds, s, a); break;
-        case 2: hipLaunchKernelGGL((mfma_gemm_kernel<G, 2, EPI>), grid, dim3(256), lds, s, a); break;
-        case 4: hipLaunchKernelGGL((mfma_gemm_kernel<G, 4, EPI>), grid, dim3(256), lds, s, a); break;
-        default: hipLaunchKernelGGL((mfma_gemm_kernel<G, 8, EPI>), grid, dim3(256), lds, s, a); break;
+        T3K_GEMM_CASE(1)
+        T3K_GEMM_CASE(2)
+        T3K_GEMM_CASE(4)
+        default: return ks8 ? launch_gemm_k<G, 8, 8, EPI>(a, tiles, s) : launch_gemm_k<G, 8, 4, EPI>(a, tiles, s);
     }
-    return hipGetLastError();
+#undef T3K_GEMM_CASE
 }
 
 template <typename G>
