@@ -156,8 +156,20 @@ __global__ __launch_bounds__(KS * 64) void mfma_gemm_kernel(GemmArgs a) {
             const int ff = 16 * tile + n;
             if (ff < a.N) {
                 const size_t o = (size_t)(m0 + m) * a.ldy + ff;
-                const float v = total(m, n);
+                float v = total(m, n);
+                if (a.bias != nullptr) v = __fadd_rn(v, a.bias[ff]);
                 a.y[o] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o], v) : v;
+            }
+        }
+    } else if (EPI == EPI_GELU) {  // gelu_tanh(c_fc(x) + b)  (R/t3.R:1303-1304)
+        for (int it = tid; it < Mc * 16; it += KS * 64) {
+            const int m = it >> 4, n = it & 15;
+            const int ff = 16 * tile + n;
+            if (ff < a.N) {
+                float v = total(m, n);
+                if (a.bias != nullptr) v = __fadd_rn(v, a.bias[ff]);
+                const float inner = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+                Act<AT>::store(static_cast<AT*>(a.yact) + (size_t)(m0 + m) * a.N + ff, 0.5f * v * (1.0f + tanhf(inner)));
             }
         }
     } else if (EPI == EPI_SWIGLU) {
@@ -181,7 +193,11 @@ __global__ __launch_bounds__(KS * 64) void mfma_gemm_kernel(GemmArgs a) {
             if (pos < 0) continue;
             const int i = i0 + p;
             float lo = total(m, p), hi = total(m, p + 8);
-            if (kind < 2) {
+            if (a.bias != nullptr) {
+                lo = __fadd_rn(lo, a.bias[hm * kHeadDim + i]);
+                hi = __fadd_rn(hi, a.bias[hm * kHeadDim + i + 32]);
+            }
+            if (kind < 2 && a.rope) {
                 const float cs = a.rope_cos[(size_t)pos * kHeadDim + i];
                 const float sn = a.rope_sin[(size_t)pos * kHeadDim + i];
                 const float nlo = __fadd_rn(__fmul_rn(lo, cs), __fmul_rn(-hi, sn));
@@ -216,6 +232,35 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restri
     const float tot = (sred[0] + sred[1]) + (sred[2] + sred[3]);
     const float rs = 1.0f / sqrtf(tot / (float)d + eps);
     for (int i = tid; i < d; i += 256) Act<AT>::store(out + (size_t)m * d + i, __fmul_rn(w[i], __fmul_rn(xr[i], rs)));
+}
+
+// ---- LayerNorm over rows (Turbo, R/t3.R:1200-1203): two-pass mean / biased variance -------------------------
+template <typename AT>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, float eps, AT* __restrict__ out, int d) {
+    __shared__ float sred[8];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float* xr = x + (size_t)m * d;
+    float sm = 0.f;
+    for (int i = tid; i < d; i += 256) sm += xr[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+    if ((tid & 63) == 0) sred[tid >> 6] = sm;
+    __syncthreads();
+    const float mean = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / (float)d;
+    float ss = 0.f;
+    for (int i = tid; i < d; i += 256) {
+        const float c = xr[i] - mean;
+        ss = fmaf(c, c, ss);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if ((tid & 63) == 0) sred[4 + (tid >> 6)] = ss;
+    __syncthreads();
+    const float var = ((sred[4] + sred[5]) + (sred[6] + sred[7])) / (float)d;
+    const float rs = 1.0f / sqrtf(var + eps);
+    for (int i = tid; i < d; i += 256)
+        Act<AT>::store(out + (size_t)m * d + i, __fadd_rn(__fmul_rn(__fmul_rn(xr[i] - mean, rs), w[i]), b[i]));
 }
 
 // ---- merge of the split-softmax attention partials into the o_proj activation rows ----------------------
@@ -291,6 +336,7 @@ hipError_t launch_gemm_g(const GemmArgs& a, int epi, hipStream_t s) {
     switch (epi) {
         case EPI_STORE: return launch_gemm_mt<G, EPI_STORE>(a, (a.N + 15) / 16, s);
         case EPI_RESID: return launch_gemm_mt<G, EPI_RESID>(a, (a.N + 15) / 16, s);
+        case EPI_GELU: return launch_gemm_mt<G, EPI_GELU>(a, (a.N + 15) / 16, s);
         case EPI_SWIGLU: return launch_gemm_mt<G, EPI_SWIGLU>(a, a.N / 16, s);
         case EPI_ROPE_KV: return launch_gemm_mt<G, EPI_ROPE_KV>(a, a.N / 16, s);
     }
@@ -304,9 +350,10 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
     if ((epilogue == EPI_STORE || epilogue == EPI_RESID) && (!a.y || a.ldy <= 0)) return hipErrorInvalidValue;
     if (epilogue == EPI_RESID && !a.resid) return hipErrorInvalidValue;
     if (epilogue == EPI_SWIGLU && (!a.yact || (a.N % 16))) return hipErrorInvalidValue;
+    if (epilogue == EPI_GELU && !a.yact) return hipErrorInvalidValue;
     if (epilogue == EPI_ROPE_KV &&
-        (a.N != 3 * a.n_heads * kHeadDim || !a.posmap || !a.rope_cos || !a.rope_sin || !a.q || !a.kcache || !a.vcache ||
-         a.max_len <= 0))
+        (a.N != 3 * a.n_heads * kHeadDim || !a.posmap || !a.q || !a.kcache || !a.vcache || a.max_len <= 0 ||
+         (a.rope && (!a.rope_cos || !a.rope_sin))))
         return hipErrorInvalidValue;
     return wdtype == 1 ? launch_gemm_g<GemmBF16>(a, epilogue, s) : launch_gemm_g<GemmF32>(a, epilogue, s);
 }
@@ -318,6 +365,16 @@ hipError_t launch_rmsnorm_rows(const float* x, const float* w, float eps, void* 
         hipLaunchKernelGGL(rmsnorm_rows_kernel<uint16_t>, dim3(M), dim3(256), 0, s, x, w, eps, static_cast<uint16_t*>(out), d);
     else
         hipLaunchKernelGGL(rmsnorm_rows_kernel<float>, dim3(M), dim3(256), 0, s, x, w, eps, static_cast<float*>(out), d);
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm_rows(const float* x, const float* w, const float* b, float eps, void* out, int M, int d,
+                                 int act_bf16, hipStream_t s) {
+    if (!x || !w || !b || !out || M <= 0 || d <= 0) return hipErrorInvalidValue;
+    if (act_bf16)
+        hipLaunchKernelGGL(layernorm_rows_kernel<uint16_t>, dim3(M), dim3(256), 0, s, x, w, b, eps, static_cast<uint16_t*>(out), d);
+    else
+        hipLaunchKernelGGL(layernorm_rows_kernel<float>, dim3(M), dim3(256), 0, s, x, w, b, eps, static_cast<float*>(out), d);
     return hipGetLastError();
 }
 

@@ -125,10 +125,10 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
     constexpr int E = WT::E;
     constexpr int KW = NK * kWave * E;  // K elements handled by one wave
     constexpr int K = KW * KSPLIT;
-    static_assert(EPI == EPI_STORE || EPI == EPI_RESID || (ROWS % 2 == 0), "paired epilogues need even ROWS");
+    static_assert(EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_GELU || (ROWS % 2 == 0), "paired epilogues need even ROWS");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                                          // [R][K], PRO_NORM / PRO_ATTN
-    float* part = smem + (PRO != PRO_PLAIN ? R * K : 0);       // [NW][max(ROWS,1)][R] scratch
+    float* part = smem + (PRO != PRO_PLAIN ? R * K : 0);       // [NW][max(ROWS,2)][R] scratch
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
     const int grp = wave / KSPLIT, kpart = wave % KSPLIT, ngrp = nw / KSPLIT;
@@ -174,7 +174,8 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
     // critical path) or the split-softmax partials of the attention kernel (ATTN, merged once per block)
     float xv[R][NK][E];
     constexpr int NXJ = (K / 4 + 127) / 128;   // float4 slices per thread per row at >= 128 threads
-    float4 gx[PRO == PRO_NORM ? NXJ : 1], vx[PRO == PRO_NORM ? R : 1][PRO == PRO_NORM ? NXJ : 1];
+    constexpr bool kNormPro = (PRO == PRO_NORM || PRO == PRO_LNORM);
+    float4 gx[kNormPro ? NXJ : 1], vx[kNormPro ? R : 1][kNormPro ? NXJ : 1];
     float rs_row[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) rs_row[r] = 1.0f;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
                 pav[it][sp] = *reinterpret_cast<const float4*>(a.pacc + (b + sc) * kHeadDim + dd);
             }
         }
-    } else if (PRO == PRO_NORM) {
+    } else if (PRO == PRO_NORM || PRO == PRO_LNORM) {
         // the block loads x and the norm weight ONCE (each thread a slice) instead of once per wave:
         // per-wave copies cost more L1 bandwidth than the weight stream itself (12 KiB per wave)
 #pragma unroll
@@ -274,6 +275,73 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
         for (int r = 0; r < R; ++r) {
             float t = 0.f;
             for (int ww = 0; ww < nw; ++ww) t += part[ww * R + r];
+            rs_row[r] = 1.0f / sqrtf(t / (float)K + a.eps);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < NK; ++q)
+#pragma unroll
+                for (int e4 = 0; e4 < E; e4 += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(xs + r * K + kbase + q * kWave * E + lane * E + e4);
+                    xv[r][q][e4 + 0] = v.x; xv[r][q][e4 + 1] = v.y; xv[r][q][e4 + 2] = v.z; xv[r][q][e4 + 3] = v.w;
+                }
+    } else if (PRO == PRO_LNORM) {
+        // LayerNorm (R/t3.R:1200-1203): xs = w_ln * (x - mean); the scalar rsqrt(var + eps) is applied to the
+        // dot products in the epilogue and the LayerNorm bias is folded into `bias` at load time
+        // (bias_eff[n] = bias[n] + sum_k W[n][k] * b_ln[k]).  Two-pass mean / variance.
+        float sm[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) sm[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NXJ; ++j) {
+            const int i = (tid + j * nthr) * 4;
+            if (i < K) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) sm[r] += (vx[r][j].x + vx[r][j].y) + (vx[r][j].z + vx[r][j].w);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float t = wave_sum(sm[r]);
+            if (lane == 0) part[wave * R + r] = t;
+        }
+        __syncthreads();
+        float ssq[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float t = 0.f;
+            for (int ww = 0; ww < nw; ++ww) t += part[ww * R + r];
+            sm[r] = t / (float)K;   // mean
+            ssq[r] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NXJ; ++j) {
+            const int i = (tid + j * nthr) * 4;
+            if (i < K) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float4 v = vx[r][j];
+                    v.x -= sm[r]; v.y -= sm[r]; v.z -= sm[r]; v.w -= sm[r];
+                    ssq[r] = fmaf(v.x, v.x, ssq[r]); ssq[r] = fmaf(v.y, v.y, ssq[r]);
+                    ssq[r] = fmaf(v.z, v.z, ssq[r]); ssq[r] = fmaf(v.w, v.w, ssq[r]);
+                    float4 o;
+                    o.x = __fmul_rn(gx[j].x, v.x); o.y = __fmul_rn(gx[j].y, v.y);
+                    o.z = __fmul_rn(gx[j].z, v.z); o.w = __fmul_rn(gx[j].w, v.w);
+                    *reinterpret_cast<float4*>(xs + r * K + i) = o;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float t = wave_sum(ssq[r]);
+            if (lane == 0) part[(nw + wave) * R + r] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float t = 0.f;
+            for (int ww = 0; ww < nw; ++ww) t += part[(nw + ww) * R + r];
             rs_row[r] = 1.0f / sqrtf(t / (float)K + a.eps);
         }
 #pragma unroll
@@ -369,7 +437,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 acc[j][r] = wave_sum(acc[j][r]);
-                if (PRO == PRO_NORM) acc[j][r] = __fmul_rn(acc[j][r], rs_row[r]);
+                if (PRO == PRO_NORM || PRO == PRO_LNORM) acc[j][r] = __fmul_rn(acc[j][r], rs_row[r]);
             }
 
         if (KSPLIT > 1) {
@@ -399,7 +467,22 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
 #endif
         if (!live) continue;
 
-        if (EPI == EPI_STORE || EPI == EPI_RESID) {
+        if (EPI == EPI_GELU) {
+            // gelu_tanh(c_fc(x) + b)  (R/t3.R:1303-1304)
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (lane == j * R + r) {
+                        const int n = ROWS * c + j;
+                        if (n < a.N) {
+                            float v = acc[j][r];
+                            if (a.bias != nullptr) v = __fadd_rn(v, a.bias[n]);
+                            const float inner = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+                            a.y[(size_t)r * a.ldy + n] = 0.5f * v * (1.0f + tanhf(inner));
+                        }
+                    }
+        } else if (EPI == EPI_STORE || EPI == EPI_RESID) {
             const bool first = (cb == (int)blockIdx.x * ngrp);
 #pragma unroll
             for (int j = 0; j < ROWS; ++j)
@@ -409,11 +492,13 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
                         const int n = ROWS * c + j;
                         if (n < a.N) {
                             const size_t o = (size_t)r * a.ldy + n;
+                            float v = acc[j][r];
+                            if (a.bias != nullptr) v = __fadd_rn(v, a.bias[n]);
                             if (EPI == EPI_RESID) {
                                 const float res = first ? e_res : a.resid[o];
-                                a.y[o] = __fadd_rn(res, acc[j][r]);
+                                a.y[o] = __fadd_rn(res, v);
                             } else {
-                                a.y[o] = acc[j][r];
+                                a.y[o] = v;
                             }
                         }
                     }
@@ -445,7 +530,11 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
                         if (pos >= 0) {
                             const int i = i0 + jj;
                             float lo = acc[jj][r], hi = acc[jj + HP][r];
-                            if (kind < 2) {
+                            if (a.bias != nullptr) {
+                                lo = __fadd_rn(lo, a.bias[hm * kHeadDim + i]);
+                                hi = __fadd_rn(hi, a.bias[hm * kHeadDim + i + 32]);
+                            }
+                            if (kind < 2 && a.rope) {
                                 // q*cos + rotate_half(q)*sin, each product rounded (R/llama.R:184-185);
                                 // cos/sin rows repeat with period 32, so one (cos, sin) serves both halves
                                 const float cs = first ? e_c : a.rope_cur[(size_t)(2 * r) * kHeadDim + i];
@@ -882,13 +971,13 @@ hipError_t launch_gemv_t(const GemvArgs& a, hipStream_t s) {
     // waves per block: aim at one block per CU (256 CUs) with every load of the launch in flight at once
     int nw = a.waves > 0 ? a.waves : 4;
     if (PRO == PRO_ATTN) nw = 4;   // the merge prologue is written for a 256-thread block
-    if (PRO == PRO_NORM && nw < 2) nw = 2;   // the norm prologue slices x over >= 128 threads
+    if ((PRO == PRO_NORM || PRO == PRO_LNORM) && nw < 2) nw = 2;   // the norm prologue slices x over >= 128 threads
     if (nw % KSPLIT) nw = ((nw + KSPLIT - 1) / KSPLIT) * KSPLIT;
     if (nw > 8) nw = 8;
     const int per_block = nw / KSPLIT;
     int grid = (n_chunks + per_block - 1) / per_block;
     if (grid > 256 * 8) grid = 256 * 8;
-    const size_t lds = ((PRO != PRO_PLAIN ? (size_t)R * K : 0) + (size_t)nw * ROWS * R + 32) * sizeof(float);
+    const size_t lds = ((PRO != PRO_PLAIN ? (size_t)R * K : 0) + (size_t)nw * (ROWS < 2 ? 2 : ROWS) * R + 32) * sizeof(float);
     auto kfn = gemv_kernel<WT, R, NK, KSPLIT, ROWS, EPI, PRO>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -902,6 +991,14 @@ hipError_t launch_gemv_t(const GemvArgs& a, hipStream_t s) {
 template <typename WT, int R, int NK>
 hipError_t launch_gemv_rn(const GemvArgs& a, int epi, int ksplit, hipStream_t s) {
     const int rpc = a.rows_per_chunk;
+    if (a.layernorm && ksplit == 1) {   // Turbo (GPT-2) linears behind a LayerNorm
+        switch (epi) {
+            case EPI_STORE: return launch_gemv_t<WT, R, NK, 1, 2, EPI_STORE, PRO_LNORM>(a, s);
+            case EPI_ROPE_KV: return launch_gemv_t<WT, R, NK, 1, 2, EPI_ROPE_KV, PRO_LNORM>(a, s);
+            case EPI_GELU: return launch_gemv_t<WT, R, NK, 1, 2, EPI_GELU, PRO_LNORM>(a, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     if (ksplit == 1) {
         switch (epi) {
             case EPI_STORE:
@@ -966,6 +1063,7 @@ hipError_t launch_gemv(const GemvArgs& a, int epilogue, int wdtype, hipStream_t 
     if (a.W == nullptr || a.y == nullptr || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
     const bool norm = (epilogue != EPI_RESID);
     if (norm && (a.ln_w == nullptr || a.x == nullptr)) return hipErrorInvalidValue;
+    if (epilogue == EPI_GELU && !a.layernorm) return hipErrorInvalidValue;
     if (epilogue == EPI_RESID) {
         if (a.resid == nullptr) return hipErrorInvalidValue;
         if (a.pacc != nullptr) {  // attention-merge prologue

@@ -11,12 +11,14 @@ enum Epilogue : int {
     EPI_RESID = 1,    // y[r][n] = resid[r][n] + acc                     (o_proj / down_proj, R/llama.R:355,360)
     EPI_ROPE_KV = 2,  // RoPE on q,k; q -> qbuf, k,v -> cache at rowpos  (R/llama.R:227-245; src/t3_decode.cpp:134-148)
     EPI_SWIGLU = 3,   // y[r][n] = silu(gate_n) * up_n                   (R/llama.R:305-308)
+    EPI_GELU = 4,     // y[r][n] = gelu_tanh(acc + bias)                 (Turbo c_fc, R/t3.R:1303-1304)
 };
 
 enum Prologue : int {
     PRO_PLAIN = 0,  // activation rows used as they are
     PRO_NORM = 1,   // fused RMSNorm (R/llama.R:65-72)
     PRO_ATTN = 2,   // merge of the split-softmax attention partials
+    PRO_LNORM = 3,  // fused LayerNorm (Turbo, R/t3.R:1200-1203); its bias term is folded into `bias`
 };
 
 #ifdef T3K_STAMPS
@@ -27,7 +29,10 @@ enum Prologue : int {
 struct GemvArgs {
     const void* W = nullptr;      // [N, K] row-major (row = output feature), fp32 or bf16
     const float* x = nullptr;     // [rows, K]
-    const float* ln_w = nullptr;  // RMSNorm weight [K] (norm prologue) or nullptr
+    const float* ln_w = nullptr;  // RMSNorm / LayerNorm weight [K] (norm prologue) or nullptr
+    int layernorm = 0;            // 1: LayerNorm prologue (mean removed), else RMSNorm
+    const float* bias = nullptr;  // [N] added to the dot products (Turbo linears), or nullptr
+    int rope = 1;                 // EPI_ROPE_KV: 0 = store q/k/v without rotation (GPT-2)
     float eps = 1e-5f;
     int N = 0, K = 0;
     int rows = 0;                 // activation rows in this launch (<= 4)
@@ -76,7 +81,9 @@ struct GemmArgs {
     float* y = nullptr;           // EPI_STORE / EPI_RESID output [M, ldy] fp32
     const float* resid = nullptr; // may alias y
     int ldy = 0;
-    void* yact = nullptr;         // EPI_SWIGLU output [M, N/2] in the activation type
+    void* yact = nullptr;         // EPI_SWIGLU output [M, N/2] / EPI_GELU output [M, N], activation type
+    const float* bias = nullptr;  // [N] or nullptr
+    int rope = 1;
     // EPI_ROPE_KV
     const int* posmap = nullptr;  // [M] cache slot of item m (< 0 = inactive)
     const int* rowmap = nullptr;  // [M] cache row of item m (nullptr = identity)
@@ -104,7 +111,7 @@ struct SamplerArgs {
     const float* logits = nullptr;  // [n_utt*rpu, V]
     int V = 0, rpu = 1, n_utt = 0;
     float cfg_w = 0.f, temperature = 1.f, top_p = 1.f, min_p = 0.f, penalty = 1.f;
-    int variant = 0, top_k = 0, stop_token = -1, mask_stop = 0, max_new_tokens = 0;
+    int variant = 0, top_k = 0, stop_token = -1, start_token = -1, mask_stop = 0, max_new_tokens = 0;
     unsigned long long seed = 0;
     uint8_t* seen = nullptr;      // [n_utt, V]
     int* tokens = nullptr;        // [n_utt, cap]
@@ -139,6 +146,8 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t s);
 hipError_t launch_prefill_embed(const EmbedArgs& a, hipStream_t s);
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t s);
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t s);
+hipError_t launch_layernorm_rows(const float* x, const float* w, const float* b, float eps, void* out, int M, int d,
+                                 int act_bf16, hipStream_t s);
 hipError_t launch_rmsnorm_rows(const float* x, const float* w, float eps, void* out, int M, int d, int act_bf16,
                                hipStream_t s);
 hipError_t launch_attn_merge(const float* pm, const float* pl, const float* pacc, const int* posmap, void* out, int M,

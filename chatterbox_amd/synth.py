@@ -71,6 +71,69 @@ def synth_llama_weights(dims: T3Dims, seed: int = 1234, head_scale: float = 1.0)
     return w
 
 
+@dataclass(frozen=True)
+class TurboDims:
+    """Shapes of the GPT-2 backbone Turbo T3 (R/t3.R:1154-1179, 1347-1357)."""
+    hidden_size: int = 1024
+    n_head: int = 16
+    n_layer: int = 24
+    speech_vocab: int = 6563
+    start_speech_token: int = 6561
+    stop_speech_token: int = 6562
+
+
+TURBO_FULL = TurboDims()
+TURBO_TINY = TurboDims(hidden_size=512, n_head=8, n_layer=2, speech_vocab=900, start_speech_token=890,
+                       stop_speech_token=891)
+
+
+def synth_turbo_weights(dims: TurboDims, seed: int = 4321, head_scale: float = 1.0) -> Dict[str, np.ndarray]:
+    """Turbo checkpoint keys of R/t3.R:1508-1549; linear weights stored [out, in] as the
+    reference's loader copies them (R/t3.R:1540-1549)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    d, V = dims.hidden_size, dims.speech_vocab
+    F = 4 * d
+
+    def lin(o, i):
+        return (rng.standard_normal((o, i), dtype=F32) * F32(0.02)).astype(F32)
+
+    def vec(n, mean, std):
+        return (F32(mean) + rng.standard_normal(n, dtype=F32) * F32(std)).astype(F32)
+
+    w: Dict[str, np.ndarray] = {}
+    for i in range(dims.n_layer):
+        p = f"tfmr.h.{i}."
+        w[p + "ln_1.weight"] = vec(d, 1.0, 0.1)
+        w[p + "ln_1.bias"] = vec(d, 0.0, 0.05)
+        w[p + "attn.c_attn.weight"] = lin(3 * d, d)
+        w[p + "attn.c_attn.bias"] = vec(3 * d, 0.0, 0.02)
+        w[p + "attn.c_proj.weight"] = lin(d, d)
+        w[p + "attn.c_proj.bias"] = vec(d, 0.0, 0.02)
+        w[p + "ln_2.weight"] = vec(d, 1.0, 0.1)
+        w[p + "ln_2.bias"] = vec(d, 0.0, 0.05)
+        w[p + "mlp.c_fc.weight"] = lin(F, d)
+        w[p + "mlp.c_fc.bias"] = vec(F, 0.0, 0.02)
+        w[p + "mlp.c_proj.weight"] = lin(d, F)
+        w[p + "mlp.c_proj.bias"] = vec(d, 0.0, 0.02)
+    w["tfmr.ln_f.weight"] = vec(d, 1.0, 0.1)
+    w["tfmr.ln_f.bias"] = vec(d, 0.0, 0.05)
+    w["speech_emb.weight"] = lin(V, d)
+    w["speech_head.weight"] = (lin(V, d) * F32(head_scale)).astype(F32)
+    w["speech_head.bias"] = vec(V, 0.0, 0.02)
+    return w
+
+
+def ensure_turbo_checkpoint(dims: TurboDims, seed: int = 4321, root: str | None = None, head_scale: float = 1.0) -> str:
+    root = root or os.environ.get("T3MI_SYNTH_DIR", "/tmp/t3mi_synth")
+    os.makedirs(root, exist_ok=True)
+    tag = f"t3turbo_L{dims.n_layer}_d{dims.hidden_size}_V{dims.speech_vocab}_s{seed}" + (
+        "" if head_scale == 1.0 else f"_h{head_scale:g}")
+    path = os.path.join(root, tag + ".safetensors")
+    if not os.path.exists(path):
+        write_safetensors(synth_turbo_weights(dims, seed, head_scale), path)
+    return path
+
+
 def synth_embeds(rows: int, s0: int, d: int, seed: int) -> np.ndarray:
     """Prompt embeddings ~ N(0, .53^2) (the std of the real activations in the
     reference's outputs/cond_enc_debug.safetensors), shape [rows, s0, d]."""

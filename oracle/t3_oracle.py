@@ -416,3 +416,158 @@ def t3_inference(model: LlamaOracle, embeds: np.ndarray, p: SampleParams, utt: i
         hidden, past = model.forward(nxt, past)
         last = hidden[:, -1, :]
     return tr
+
+
+# --------------------------------------------------------------------------
+# Turbo T3: GPT-2 medium backbone (R/t3.R:1190-1410) + sampler (R/t3.R:1688-1742)
+# --------------------------------------------------------------------------
+
+@dataclass
+class TurboConfig:
+    hidden_size: int = 1024
+    n_head: int = 16
+    n_layer: int = 24
+    layer_norm_epsilon: float = 1e-5
+    speech_vocab: int = 6563
+    start_speech_token: int = 6561
+    stop_speech_token: int = 6562
+
+
+def layer_norm(x: np.ndarray, w: np.ndarray, b: np.ndarray, eps: float) -> np.ndarray:
+    """nnf_layer_norm (R/t3.R:1200-1203): biased variance, fp32."""
+    x = x.astype(F32)
+    mu = x.mean(axis=-1, keepdims=True, dtype=F32)
+    xc = (x - mu).astype(F32)
+    var = np.mean(np.square(xc), axis=-1, keepdims=True, dtype=F32)
+    return ((xc / np.sqrt(var + F32(eps), dtype=F32)).astype(F32) * w + b).astype(F32)
+
+
+def gelu_tanh(x: np.ndarray) -> np.ndarray:
+    """nnf_gelu(approximate = "tanh") (R/t3.R:1304)."""
+    x = x.astype(F32)
+    c = F32(math.sqrt(2.0 / math.pi))
+    inner = (c * (x + F32(0.044715) * x * x * x)).astype(F32)
+    return (F32(0.5) * x * (F32(1.0) + np.tanh(inner, dtype=F32))).astype(F32)
+
+
+class GPT2Oracle:
+    """gpt2_model + t3_model_turbo heads over the reference's turbo key names (R/t3.R:1508-1549).
+    No positional term of any kind is added (wpe is loaded but unused, R/t3.R:1387-1409)."""
+
+    def __init__(self, weights: Dict[str, np.ndarray], cfg: TurboConfig):
+        self.w = weights
+        self.cfg = cfg
+
+    def forward(self, embeds: np.ndarray, past: Optional[list] = None):
+        cfg, w = self.cfg, self.w
+        x = embeds.astype(F32)
+        R, S, d = x.shape
+        H = cfg.n_head
+        Dh = d // H
+        new_past = []
+        for i in range(cfg.n_layer):
+            p = f"tfmr.h.{i}."
+            h = layer_norm(x, w[p + "ln_1.weight"], w[p + "ln_1.bias"], cfg.layer_norm_epsilon)
+            qkv = linear(h, w[p + "attn.c_attn.weight"], w[p + "attn.c_attn.bias"])
+            q, k, v = [t.reshape(R, S, H, Dh).transpose(0, 2, 1, 3) for t in np.split(qkv, 3, axis=-1)]
+            if past is not None:
+                k = np.concatenate([past[i][0], k], axis=2)
+                v = np.concatenate([past[i][1], v], axis=2)
+            new_past.append((k, v))
+            mask = None
+            if S > 1 and past is None:                      # is_causal = TRUE in prefill (R/t3.R:1257)
+                mask = np.triu(np.full((S, S), -np.inf, dtype=F32), k=1)[None, None]
+            a = sdpa(q, k, v, mask).transpose(0, 2, 1, 3).reshape(R, S, d)
+            x = (x + linear(a, w[p + "attn.c_proj.weight"], w[p + "attn.c_proj.bias"])).astype(F32)
+            h = layer_norm(x, w[p + "ln_2.weight"], w[p + "ln_2.bias"], cfg.layer_norm_epsilon)
+            h = gelu_tanh(linear(h, w[p + "mlp.c_fc.weight"], w[p + "mlp.c_fc.bias"]))
+            x = (x + linear(h, w[p + "mlp.c_proj.weight"], w[p + "mlp.c_proj.bias"])).astype(F32)
+        x = layer_norm(x, w["tfmr.ln_f.weight"], w["tfmr.ln_f.bias"], cfg.layer_norm_epsilon)
+        return x, new_past
+
+    def speech_logits(self, hidden_last: np.ndarray) -> np.ndarray:
+        return linear(hidden_last, self.w["speech_head.weight"], self.w["speech_head.bias"])   # R/t3.R:1444
+
+
+@dataclass
+class TurboParams:
+    """Arguments of t3_inference_turbo (R/t3.R:1578-1580)."""
+    max_new_tokens: int = 1000
+    temperature: float = 0.8
+    top_k: int = 1000
+    top_p: float = 0.95
+    repetition_penalty: float = 1.2
+    seed: int = 0
+
+
+def turbo_sampling_tail(logits: np.ndarray, pen_ids0: Sequence[int], p: TurboParams, u: float) -> TailResult:
+    """.turbo_sample_token (R/t3.R:1688-1742), 0-indexed: sign-aware penalty, /T, top-k by the
+    k-th largest value, top-p on the softmax of the sorted logits (first always kept), softmax over
+    the survivors.  The draw is the build's inverse-CDF rule (see sampling_tail)."""
+    lg = logits.astype(F32).copy()
+    V = lg.shape[0]
+    if p.repetition_penalty != 1.0 and len(pen_ids0) > 0:
+        ids = np.unique(np.asarray(list(pen_ids0), dtype=np.int64))
+        ids = ids[(ids >= 0) & (ids < V)]
+        pos = lg[ids] > 0
+        lg[ids] = np.where(pos, lg[ids] / F32(p.repetition_penalty), lg[ids] * F32(p.repetition_penalty)).astype(F32)
+    if p.temperature > 0 and p.temperature != 1.0:
+        lg = (lg / F32(p.temperature)).astype(F32)
+    if 0 < p.top_k < V:
+        kth = np.sort(lg)[::-1][p.top_k - 1]
+        lg = np.where(lg < kth, F32(-np.inf), lg).astype(F32)
+    order = np.argsort(-lg, kind="stable")
+    sl = lg[order]
+    n_fin = int(np.count_nonzero(np.isfinite(sl)))
+    e = np.exp((sl - sl[0]).astype(F32), dtype=F32)
+    sp = (e / e.sum(dtype=F32)).astype(F32)
+    cum = np.cumsum(sp.astype(np.float64)).astype(F32)
+    if p.top_p < 1.0:
+        mask = cum > F32(p.top_p)
+        mask[0] = False
+        nz = int(np.count_nonzero(~mask[:n_fin]))
+    else:
+        nz = n_fin
+    sup_idx = order[:nz].copy()
+    sup_p = (sp[:nz] / sp[:nz].sum(dtype=F32)).astype(F32)
+    target = F32(F32(u) * cum[nz - 1])
+    j = min(int(np.count_nonzero(cum[:nz] <= target)), nz - 1)
+    return TailResult(int(sup_idx[j]), sup_idx, sup_p, lg, cum[:nz].copy(), float(target))
+
+
+def t3_inference_turbo(model: GPT2Oracle, embeds: np.ndarray, p: TurboParams, utt: int = 0,
+                       keep_logits: bool = True, forced_tokens: Optional[Sequence[int]] = None,
+                       mask_stop: bool = False) -> InferenceTrace:
+    """R/t3.R:1578-1677 after prepare_input_embeds: batch 1, no CFG, no positional embedding for the
+    generated tokens; first token from the prefill logits, then up to max_new_tokens more; the
+    returned trace keeps the stop token (the R wrapper strips a trailing one, :1667-1671).
+    Penalty ids (Q17): step 0 uses the raw BOS id as a 1-based column (= column BOS-1); later
+    steps use the generated tokens only."""
+    cfg = model.cfg
+    tr = InferenceTrace()
+    hidden, past = model.forward(embeds)
+    last = hidden[:, -1, :]
+    gen: List[int] = []
+    for step in range(p.max_new_tokens + 1):
+        logits = model.speech_logits(last)                    # [1,V]
+        if keep_logits:
+            tr.raw_logits.append(logits.copy())
+        lc = logits[0].astype(F32).copy()
+        if mask_stop:
+            lc[cfg.stop_speech_token] = -np.inf
+        pen = [cfg.start_speech_token - 1] if step == 0 else gen
+        tail = turbo_sampling_tail(lc, pen, p, counter_uniform(p.seed, utt, step))
+        tok = tail.token if forced_tokens is None else int(forced_tokens[step])
+        if keep_logits:
+            tr.tails.append(tail)
+        tr.tokens.append(tok)
+        gen.append(tok)
+        if tok == cfg.stop_speech_token:
+            tr.hit_eos = True
+            break
+        if step >= p.max_new_tokens:
+            break
+        e = model.w["speech_emb.weight"][tok].astype(F32)     # no position embedding (R/t3.R:1628)
+        hidden, past = model.forward(e[None, None, :], past)
+        last = hidden[:, -1, :]
+    return tr

@@ -120,3 +120,75 @@ def test_sampling_tail_matches_torch(variant, top_p, min_p):
     assert nz == len(t.sorted_idx)
     assert np.array_equal(si[:nz].numpy(), t.sorted_idx)
     np.testing.assert_allclose(sp[:nz].numpy(), t.sorted_probs, rtol=2e-6, atol=1e-9)
+
+
+def test_turbo_forward_and_tail_match_torch():
+    """GPT-2 blocks (LayerNorm, fused c_attn + bias, GELU-tanh) and the turbo sampler vs libtorch ops."""
+    dims = synth.TURBO_TINY
+    w = synth.synth_turbo_weights(dims, 9)
+    cfg = O.TurboConfig(hidden_size=dims.hidden_size, n_head=dims.n_head, n_layer=dims.n_layer,
+                        speech_vocab=dims.speech_vocab, start_speech_token=dims.start_speech_token,
+                        stop_speech_token=dims.stop_speech_token)
+    m = O.GPT2Oracle(w, cfg)
+    emb = synth.synth_embeds(1, 7, dims.hidden_size, 3)
+    tw = {k: torch.from_numpy(v) for k, v in w.items()}
+
+    def tforward(x, past):
+        x = torch.from_numpy(x)
+        R, S, d = x.shape
+        H = cfg.n_head
+        new = []
+        for i in range(cfg.n_layer):
+            p = f"tfmr.h.{i}."
+            h = Fn.layer_norm(x, (d,), tw[p + "ln_1.weight"], tw[p + "ln_1.bias"], 1e-5)
+            q, k, v = Fn.linear(h, tw[p + "attn.c_attn.weight"], tw[p + "attn.c_attn.bias"]).split(d, dim=2)
+            q, k, v = [t.view(R, S, H, d // H).transpose(1, 2) for t in (q, k, v)]
+            if past is not None:
+                k = torch.cat([past[i][0], k], 2)
+                v = torch.cat([past[i][1], v], 2)
+            new.append((k, v))
+            a = Fn.scaled_dot_product_attention(q, k, v, is_causal=(S > 1 and past is None))
+            a = a.transpose(1, 2).contiguous().view(R, S, d)
+            x = x + Fn.linear(a, tw[p + "attn.c_proj.weight"], tw[p + "attn.c_proj.bias"])
+            h = Fn.layer_norm(x, (d,), tw[p + "ln_2.weight"], tw[p + "ln_2.bias"], 1e-5)
+            h = Fn.gelu(Fn.linear(h, tw[p + "mlp.c_fc.weight"], tw[p + "mlp.c_fc.bias"]), approximate="tanh")
+            x = x + Fn.linear(h, tw[p + "mlp.c_proj.weight"], tw[p + "mlp.c_proj.bias"])
+        return Fn.layer_norm(x, (d,), tw["tfmr.ln_f.weight"], tw["tfmr.ln_f.bias"], 1e-5), new
+
+    h_o, past_o = m.forward(emb)
+    with torch.no_grad():
+        h_t, past_t = tforward(emb, None)
+    np.testing.assert_allclose(h_o, h_t.numpy(), rtol=0, atol=3e-5)
+    nxt = synth.synth_embeds(1, 1, dims.hidden_size, 4)
+    h_o2, _ = m.forward(nxt, past_o)
+    with torch.no_grad():
+        h_t2, _ = tforward(nxt, past_t)
+    np.testing.assert_allclose(h_o2, h_t2.numpy(), rtol=0, atol=3e-5)
+
+    # sampler (R/t3.R:1688-1742) on wide logits
+    rng = np.random.default_rng(5)
+    lg = (rng.standard_normal(dims.speech_vocab) * 3).astype(np.float32)
+    for top_k, top_p in [(50, 0.95), (1000, 0.8), (0, 1.0), (20, 1.0)]:
+        p = O.TurboParams(top_k=top_k, top_p=top_p)
+        t = O.turbo_sampling_tail(lg, [3, 11], p, 0.0)
+        x = torch.from_numpy(lg.copy())
+        ids = torch.tensor([3, 11])
+        sel = x[ids]
+        x[ids] = torch.where(sel > 0, sel / 1.2, sel * 1.2)
+        x = x / 0.8
+        if 0 < top_k < x.numel():
+            x[x < torch.topk(x, top_k)[0].min()] = -float("inf")
+        if top_p < 1.0:
+            sl, si = torch.sort(x, descending=True, stable=True)
+            cp = torch.cumsum(torch.softmax(sl, -1), -1)
+            msk = cp > top_p
+            msk[0] = False
+            rem = torch.zeros_like(msk).scatter(0, si, msk)
+            x[rem] = -float("inf")
+        pr = torch.softmax(x, -1)
+        sp, si = torch.sort(pr, descending=True, stable=True)
+        nz = int((pr > 0).sum()) if top_p < 1.0 or top_k > 0 else x.numel()
+        nz = min(nz, int(torch.isfinite(x).sum()))
+        assert nz == len(t.sorted_idx)
+        assert np.array_equal(si[:nz].numpy(), t.sorted_idx)
+        np.testing.assert_allclose(sp[:nz].numpy(), t.sorted_probs, rtol=3e-6, atol=1e-9)
