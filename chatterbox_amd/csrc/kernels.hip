@@ -711,6 +711,15 @@ __device__ __forceinline__ float counter_uniform(unsigned long long seed, unsign
     return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
+// order-preserving map float -> u32 (larger float = larger integer; -inf maps above 0, the sort padding)
+__device__ __forceinline__ uint32_t mono_key(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float mono_value(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
 __device__ __forceinline__ int next_pow2(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -739,6 +748,7 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
     const float* lc = a.logits + (size_t)u * a.rpu * V;
     const uint8_t* seen = a.seen + (size_t)u * V;
     const bool use_cfg = a.cfg_w > 0.f && a.rpu > 1;
+    const bool turbo = a.variant == 2;   // .turbo_sample_token (R/t3.R:1688-1742)
 
     // 1. CFG, penalty, temperature  (R/t3.R:518-537)
     float lmax = -INFINITY;
@@ -747,15 +757,22 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
         float l = lc[v];
         if (use_cfg) l = __fadd_rn(l, __fmul_rn(a.cfg_w, __fsub_rn(l, lc[V + v])));
         if (a.mask_stop && v == a.stop_token) l = -INFINITY;
-        if (a.penalty != 1.0f && seen[v]) {
-            if (a.variant == 2) l = (l > 0.f) ? __fdiv_rn(l, a.penalty) : __fmul_rn(l, a.penalty);  // R/t3.R:1699-1708
-            else l = __fdiv_rn(l, a.penalty);                                                       // R/t3.R:531 (Q2)
+        if (a.penalty != 1.0f) {
+            if (turbo) {
+                // R/t3.R:1699-1708: sign-aware; step 0 penalises column BOS-1 only (Q17), later the generated ids
+                const bool hit = step == 0 ? (v == a.start_token - 1) : (seen[v] != 0);
+                if (hit) l = (l > 0.f) ? __fdiv_rn(l, a.penalty) : __fmul_rn(l, a.penalty);
+            } else if (seen[v]) {
+                l = __fdiv_rn(l, a.penalty);                                                        // R/t3.R:531 (Q2)
+            }
         }
-        if (a.temperature != 1.0f) l = __fdiv_rn(l, a.temperature);
+        if (a.temperature != 1.0f && !(turbo && !(a.temperature > 0.f))) l = __fdiv_rn(l, a.temperature);
         lg[v] = l;
         lmax = fmaxf(lmax, l);
     }
     lmax = block_reduce_max(lmax, scratch);
+    float s2 = 1.f;
+    if (!turbo) {
     // 2. softmax (R/t3.R:540)
     float se = 0.f;
     for (int v = tid; v < V; v += kSampThreads) {
@@ -773,7 +790,7 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
     pmax = block_reduce_max(pmax, scratch);
     // 3. min-p in probability space + renorm (R/t3.R:543-548, Q5)
     const float thr = __fmul_rn(a.min_p, pmax);
-    float s2 = 0.f;
+    s2 = 0.f;
     for (int v = tid; v < V; v += kSampThreads) {
         float p = lg[v];
         if (p < thr) p = 0.f;
@@ -781,6 +798,7 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
         s2 += p;
     }
     s2 = block_reduce_sum(s2, scratch);
+    }  // !turbo
     int tok;
     int kkeep;
     float s3;
@@ -789,9 +807,19 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
         // arg-max of the filtered distribution with ties to the lowest id -- no sort needed.
         unsigned long long best = 0ull;
         for (int v = tid; v < V; v += kSampThreads) {
-            const float p = __fdiv_rn(lg[v], s2);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(p) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)v);
-            if (p > 0.f && key > best) best = key;
+            unsigned bits;
+            bool valid;
+            if (turbo) {   // arg-max of the filtered logits: top-k / top-p keep the first sorted entry (R/t3.R:1722-1727)
+                const float l = lg[v];
+                bits = mono_key(l);
+                valid = l > -INFINITY;
+            } else {
+                const float p = __fdiv_rn(lg[v], s2);
+                bits = __float_as_uint(p);
+                valid = p > 0.f;
+            }
+            const unsigned long long key = ((unsigned long long)bits << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)v);
+            if (valid && key > best) best = key;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -807,22 +835,65 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
         for (int i = 1; i < kSampThreads / 64; ++i) best = sk[i] > best ? sk[i] : best;
         kkeep = best ? 1 : 0;
         tok = best ? (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull)) : -1;
-        s3 = __uint_as_float((unsigned)(best >> 32));
+        s3 = turbo ? 1.0f : __uint_as_float((unsigned)(best >> 32));
         if (tid == 0) {
-            kp[0] = (unsigned)(best >> 32);
+            kp[0] = turbo ? __float_as_uint(1.0f) : (unsigned)(best >> 32);
             ki[0] = (uint16_t)(tok < 0 ? 0xFFFF : tok);
         }
         __syncthreads();
     } else {
     // 4. compact the non-zero entries into (prob bits, id) keys
+    uint32_t kth = 0u;
+    if (turbo && a.top_k > 0 && a.top_k < V) {
+        // top-k threshold = the k-th largest value (ties kept, R/t3.R:1714-1719): radix select over the
+        // order-preserving integer image of the logits, 8 bits per pass, histogram in LDS
+        int* hist = reinterpret_cast<int*>(tot);
+        uint32_t prefix = 0u;
+        int remaining = a.top_k;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const uint32_t himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (int v = tid; v < V; v += kSampThreads) {
+                const uint32_t key = mono_key(lg[v]);
+                if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, dsel = 0;
+                for (int b = 255; b >= 0; --b) {
+                    const int c = hist[b];
+                    if (acc + c >= remaining) { dsel = b; break; }
+                    acc += c;
+                }
+                misc[3] = dsel;
+                misc[4] = remaining - acc;
+            }
+            __syncthreads();
+            prefix |= (uint32_t)misc[3] << shift;
+            remaining = misc[4];
+            __syncthreads();
+        }
+        kth = prefix;
+    }
     if (tid == 0) misc[0] = 0;
     __syncthreads();
     for (int v = tid; v < V; v += kSampThreads) {
-        const float p = __fdiv_rn(lg[v], s2);
-        if (p > 0.f) {
-            const int slot = atomicAdd(&misc[0], 1);
-            kp[slot] = __float_as_uint(p);
-            ki[slot] = (uint16_t)v;
+        if (turbo) {
+            const float l = lg[v];
+            const uint32_t key = mono_key(l);
+            if (l > -INFINITY && key >= kth) {
+                const int slot = atomicAdd(&misc[0], 1);
+                kp[slot] = key;
+                ki[slot] = (uint16_t)v;
+            }
+        } else {
+            const float p = __fdiv_rn(lg[v], s2);
+            if (p > 0.f) {
+                const int slot = atomicAdd(&misc[0], 1);
+                kp[slot] = __float_as_uint(p);
+                ki[slot] = (uint16_t)v;
+            }
         }
     }
     __syncthreads();
@@ -851,6 +922,19 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
             }
             __syncthreads();
         }
+    }
+    if (turbo) {
+        // softmax of the sorted, filtered logits (R/t3.R:1723): exp(l - l_max) / sum, as probabilities in kp[]
+        const float l0 = n > 0 ? mono_value(kp[0]) : 0.f;
+        float es = 0.f;
+        for (int i = tid; i < n; i += kSampThreads) {
+            const float e = expf(mono_value(kp[i]) - l0);
+            kp[i] = __float_as_uint(e);
+            es += e;
+        }
+        es = block_reduce_sum(es, scratch);
+        for (int i = tid; i < n; i += kSampThreads) kp[i] = __float_as_uint(__fdiv_rn(__uint_as_float(kp[i]), es));
+        __syncthreads();
     }
     // 6. inclusive cumsum in double, rounded to float per prefix (libtorch CPU cumsum semantics)
     const int CH = (npad + kSampThreads - 1) / kSampThreads;
@@ -899,6 +983,7 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
         for (int i = tid; i < n; i += kSampThreads) {
             bool keep;
             if (i == 0) keep = true;
+            else if (turbo && a.top_p >= 1.0f) keep = true;                   // R/t3.R:1722: filter only if top_p < 1
             else if (a.variant == 1) keep = !(cum[i - 1] > a.top_p);
             else keep = !(cum[i] > a.top_p);
             cnt += keep ? 1 : 0;
@@ -950,15 +1035,16 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
         a.done[u] = dn;
     }
     if (tid < a.rpu) a.rowpos[u * a.rpu + tid] = dn ? -1 : pos_next;
-    if (!dn && tid < 2 * kHeadDim) {
+    if (!dn && a.rope_cos != nullptr && tid < 2 * kHeadDim) {
         const float v = (tid < kHeadDim ? a.rope_cos : a.rope_sin)[(size_t)pos_next * kHeadDim + (tid & (kHeadDim - 1))];
         for (int rr = 0; rr < a.rpu; ++rr) a.rope_cur[((size_t)u * a.rpu + rr) * 2 * kHeadDim + tid] = v;
     }
     if (!dn) {
         const float* e = a.emb + (size_t)tok * a.d;
-        const float* pe = a.pos_emb + (size_t)(step + 1) * a.d;  // Q11: BOS holds row 0
+        // Q11: BOS holds row 0 of the position table; Turbo adds no position term (R/t3.R:1628)
+        const float* pe = a.pos_emb != nullptr ? a.pos_emb + (size_t)(step + 1) * a.d : nullptr;
         for (int i = tid; i < a.d; i += kSampThreads) {
-            const float v = __fadd_rn(e[i], pe[i]);
+            const float v = pe != nullptr ? __fadd_rn(e[i], pe[i]) : e[i];
             for (int rr = 0; rr < a.rpu; ++rr) a.x[((size_t)u * a.rpu + rr) * a.d + i] = v;
         }
     }

@@ -64,6 +64,15 @@ struct LayerW {
     const float* ln2 = nullptr;
     const void* wgu = nullptr;   // [2F, d]  gate rows then up rows
     const void* wdown = nullptr; // [d, F]
+    // Turbo (GPT-2, R/t3.R:1190-1310): wqkv = c_attn, wo = attn.c_proj, wgu = c_fc [F, d], wdown = mlp.c_proj
+    const float* ln1_b = nullptr;   // LayerNorm biases
+    const float* ln2_b = nullptr;
+    const float* b_qkv = nullptr;   // raw linear biases (many-row path: exact LayerNorm rows + bias)
+    const float* b_fc = nullptr;
+    const float* b_qkv_f = nullptr; // bias + W . b_ln  (decode GEMV path: the LayerNorm bias folded in)
+    const float* b_fc_f = nullptr;
+    const float* b_o = nullptr;
+    const float* b_down = nullptr;
 };
 
 struct Session {
@@ -96,7 +105,10 @@ struct t3mi_model {
     int rope_len = 0;
     std::vector<LayerW> layers;
     const float* norm_w = nullptr;
+    const float* norm_b = nullptr;     // Turbo ln_f bias
     const void* head_w = nullptr;
+    const float* head_b = nullptr;     // Turbo speech_head bias, raw and with ln_f's bias folded in
+    const float* head_b_f = nullptr;
     int64_t weight_bytes = 0;
     std::unique_ptr<Session> sess;
     bool use_graph = true;
@@ -182,6 +194,46 @@ struct Uploader {
             if (!t3mi::SafeTensorsFile::to_f32(*t, host.data(), err)) return fail(T3MI_ERR_IO, name + ": " + err);
             HIPCHK(hipMemcpy(dst, host.data(), n * 4, hipMemcpyHostToDevice));
         }
+        return T3MI_OK;
+    }
+    // host fp32 copy of a tensor
+    int fetch(const std::string& name, int64_t d0, int64_t d1, std::vector<float>& out) {
+        const t3mi::StTensor* t = nullptr;
+        int rc = get(name, d0, d1, &t);
+        if (rc) return rc;
+        out.resize((size_t)t->numel());
+        std::string err;
+        if (t->dtype == t3mi::StDtype::F32) std::memcpy(out.data(), t->data, out.size() * 4);
+        else if (!t3mi::SafeTensorsFile::to_f32(*t, out.data(), err)) return fail(T3MI_ERR_IO, name + ": " + err);
+        return T3MI_OK;
+    }
+    // dst_raw[n] = bias[n]; dst_fold[n] = bias[n] + sum_k W'[n][k] * b_ln[k], W' = W as the kernels stream it
+    // (rounded to bf16 when the model holds bf16 weights).  LayerNorm(x) W^T + b = rstd * ((x - mu) * g) W^T + fold.
+    int put_folded_bias(const std::string& wname, const std::string& bname, int64_t N, int64_t K,
+                        const std::vector<float>& b_ln, float* dst_raw, float* dst_fold) {
+        std::vector<float> W, b;
+        int rc;
+        if ((rc = fetch(wname, N, K, W))) return rc;
+        if ((rc = fetch(bname, N, -1, b))) return rc;
+        std::vector<float> fold((size_t)N);
+        const bool bf = m->wdtype == T3MI_W_BF16;
+        for (int64_t n = 0; n < N; ++n) {
+            double acc = 0.0;
+            const float* wr = W.data() + (size_t)n * K;
+            for (int64_t k = 0; k < K; ++k) {
+                float w = wr[k];
+                if (bf) {
+                    uint32_t u;
+                    std::memcpy(&u, &w, 4);
+                    if ((u & 0x7FFFFFFFu) <= 0x7F800000u) u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+                    std::memcpy(&w, &u, 4);
+                }
+                acc += (double)w * (double)b_ln[k];
+            }
+            fold[n] = (float)((double)b[n] + acc);
+        }
+        HIPCHK(hipMemcpy(dst_raw, b.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dst_fold, fold.data(), (size_t)N * 4, hipMemcpyHostToDevice));
         return T3MI_OK;
     }
     // streamed matrix in the model's weight dtype; dst points into wbuf
@@ -276,6 +328,104 @@ int load_llama(t3mi_model* m, const t3mi::SafeTensorsFile& st) {
     return T3MI_OK;
 }
 
+// Turbo T3: GPT-2 medium backbone.  Keys and [out, in] linear layout as load_t3_turbo_weights copies them
+// into nn_linear parameters (R/t3.R:1489-1551); tfmr.wpe / text_emb / cond_enc are not on the decode path.
+int load_turbo(t3mi_model* m, const t3mi::SafeTensorsFile& st) {
+    const t3mi::StTensor* qkv0 = st.find("tfmr.h.0.attn.c_attn.weight");
+    const t3mi::StTensor* fc0 = st.find("tfmr.h.0.mlp.c_fc.weight");
+    const t3mi::StTensor* hd = st.find("speech_head.weight");
+    if (!qkv0 || !fc0 || !hd || qkv0->shape.size() != 2 || fc0->shape.size() != 2 || hd->shape.size() != 2)
+        return fail(T3MI_ERR_IO, "checkpoint lacks the T3 Turbo tensors (tfmr.h.0.*, speech_head)");
+    m->d = (int)qkv0->shape[1];
+    if (qkv0->shape[0] != 3 * (int64_t)m->d)
+        return fail(T3MI_ERR_IO, "tfmr.h.0.attn.c_attn.weight must be [3*d, d] (nn_linear layout, R/t3.R:1220)");
+    m->F = (int)fc0->shape[0];
+    m->V = (int)hd->shape[0];
+    m->max_pos = 1 << 30;   // no learned speech position table on this path (R/t3.R:1628)
+    if (m->d % 64) return fail(T3MI_ERR_IO, "hidden size must be heads*64");
+    m->H = m->d / 64;
+    int L = 0;
+    while (st.find("tfmr.h." + std::to_string(L) + ".attn.c_attn.weight")) ++L;
+    m->n_layers = L;
+    const size_t d = m->d, F = m->F, V = m->V;
+    const size_t es = m->wdtype == T3MI_W_BF16 ? 2 : 4;
+    const size_t per_layer = (3 * d * d + d * d + F * d + d * F) * es;
+    const size_t total = per_layer * L + V * d * es;
+    // small: per layer ln1 w,b | ln2 w,b | b_qkv raw,fold | b_o | b_fc raw,fold | b_down ; ln_f w,b ; head bias raw,fold
+    const size_t small_layer = 4 * d + 2 * 3 * d + d + 2 * F + d;
+    const size_t small_total = small_layer * L + 2 * d + 2 * V;
+    HIPCHK(m->wbuf.alloc(total));
+    HIPCHK(m->small.alloc(small_total * 4));
+    HIPCHK(m->emb.alloc(V * d * 4));
+    m->weight_bytes = (int64_t)total + (int64_t)small_total * 4;
+
+    Uploader up{m, st, {}, {}};
+    char* w = m->wbuf.as<char>();
+    float* sm = m->small.as<float>();
+    m->layers.resize(L);
+    int rc;
+    std::vector<float> bln;
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "tfmr.h." + std::to_string(l) + ".";
+        LayerW& lw = m->layers[l];
+        lw.ln1 = sm;
+        if ((rc = up.put_f32(p + "ln_1.weight", d, -1, sm))) return rc;
+        sm += d;
+        lw.ln1_b = sm;
+        if ((rc = up.put_f32(p + "ln_1.bias", d, -1, sm))) return rc;
+        sm += d;
+        lw.ln2 = sm;
+        if ((rc = up.put_f32(p + "ln_2.weight", d, -1, sm))) return rc;
+        sm += d;
+        lw.ln2_b = sm;
+        if ((rc = up.put_f32(p + "ln_2.bias", d, -1, sm))) return rc;
+        sm += d;
+        lw.wqkv = w;
+        if ((rc = up.put_w(p + "attn.c_attn.weight", 3 * d, d, w))) return rc;
+        w += 3 * d * d * es;
+        if ((rc = up.fetch(p + "ln_1.bias", d, -1, bln))) return rc;
+        lw.b_qkv = sm;
+        lw.b_qkv_f = sm + 3 * d;
+        if ((rc = up.put_folded_bias(p + "attn.c_attn.weight", p + "attn.c_attn.bias", 3 * d, d, bln, sm, sm + 3 * d)))
+            return rc;
+        sm += 6 * d;
+        lw.wo = w;
+        if ((rc = up.put_w(p + "attn.c_proj.weight", d, d, w))) return rc;
+        w += d * d * es;
+        lw.b_o = sm;
+        if ((rc = up.put_f32(p + "attn.c_proj.bias", d, -1, sm))) return rc;
+        sm += d;
+        lw.wgu = w;
+        if ((rc = up.put_w(p + "mlp.c_fc.weight", F, d, w))) return rc;
+        w += F * d * es;
+        if ((rc = up.fetch(p + "ln_2.bias", d, -1, bln))) return rc;
+        lw.b_fc = sm;
+        lw.b_fc_f = sm + F;
+        if ((rc = up.put_folded_bias(p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", F, d, bln, sm, sm + F))) return rc;
+        sm += 2 * F;
+        lw.wdown = w;
+        if ((rc = up.put_w(p + "mlp.c_proj.weight", d, F, w))) return rc;
+        w += d * F * es;
+        lw.b_down = sm;
+        if ((rc = up.put_f32(p + "mlp.c_proj.bias", d, -1, sm))) return rc;
+        sm += d;
+    }
+    m->norm_w = sm;
+    if ((rc = up.put_f32("tfmr.ln_f.weight", d, -1, sm))) return rc;
+    sm += d;
+    m->norm_b = sm;
+    if ((rc = up.put_f32("tfmr.ln_f.bias", d, -1, sm))) return rc;
+    sm += d;
+    m->head_w = w;
+    if ((rc = up.put_w("speech_head.weight", V, d, w))) return rc;
+    if ((rc = up.fetch("tfmr.ln_f.bias", d, -1, bln))) return rc;
+    m->head_b = sm;
+    m->head_b_f = sm + V;
+    if ((rc = up.put_folded_bias("speech_head.weight", "speech_head.bias", V, d, bln, sm, sm + V))) return rc;
+    if ((rc = up.put_f32("speech_emb.weight", V, d, m->emb.as<float>()))) return rc;
+    return T3MI_OK;
+}
+
 // ---- one transformer pass over the rows currently in sess->x ------------------------------------
 #ifdef T3K_STAMPS
 unsigned long long* g_stamp_buf = nullptr;   // [launch][T3K_STAMP_WAVES][T3K_STAMP_SLOTS]
@@ -309,12 +459,13 @@ const char* const kKindName[K_COUNT] = {"sampler", "qkv_rope_kv", "attn_decode",
 
 int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
     const int d = m->d, F = m->F, H = m->H;
+    const bool turbo = m->variant == T3MI_VARIANT_TURBO;
     const size_t layer_kv = (size_t)s->rows * H * s->max_len * 64;
     for (int l = 0; l < m->n_layers; ++l) {
         const LayerW& lw = m->layers[l];
         float* kc = s->kc.as<float>() + layer_kv * l;
         float* vc = s->vc.as<float>() + layer_kv * l;
-        // K1: RMSNorm + QKV + RoPE + KV store
+        // K1: RMSNorm + QKV + RoPE + KV store   (Turbo: LayerNorm + c_attn + bias, no rotation)
         for (int r0 = 0; r0 < s->rows;) {
             const int rem = s->rows - r0, rg = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
             t3k::GemvArgs a;
@@ -327,6 +478,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.vcache = vc + (size_t)r0 * H * s->max_len * 64;
             a.n_heads = H; a.max_len = s->max_len;
             a.waves = m->tune[0]; a.rows_per_chunk = m->tune_rows[0];
+            if (turbo) { a.layernorm = 1; a.bias = lw.b_qkv_f; a.rope = 0; }
             T3MI_SET_STAMPS(a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_ROPE_KV, m->wdtype, m->stream));
             r0 += rg;
@@ -355,6 +507,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.rowpos = s->rowpos.as<int>() + r0;
             a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
             a.waves = m->tune[1]; a.rows_per_chunk = m->tune_rows[1];
+            a.bias = lw.b_o;
             T3MI_SET_STAMPS(a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
             r0 += rg;
@@ -365,11 +518,12 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             const int rem = s->rows - r0, rg = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
             t3k::GemvArgs a;
             a.W = lw.wgu; a.x = s->x.as<float>() + (size_t)r0 * d; a.ln_w = lw.ln2; a.eps = m->eps;
-            a.N = 2 * F; a.K = d; a.rows = rg;
+            a.N = turbo ? F : 2 * F; a.K = d; a.rows = rg;
             a.y = s->hbuf.as<float>() + (size_t)r0 * F; a.ldy = F;
             a.waves = m->tune[2]; a.rows_per_chunk = m->tune_rows[2];
+            if (turbo) { a.layernorm = 1; a.bias = lw.b_fc_f; }   // LayerNorm + c_fc + gelu_tanh (R/t3.R:1303-1304)
             T3MI_SET_STAMPS(a);
-            HIPCHK(t3k::launch_gemv(a, t3k::EPI_SWIGLU, m->wdtype, m->stream));
+            HIPCHK(t3k::launch_gemv(a, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, m->wdtype, m->stream));
             r0 += rg;
         }
         if (tm) tm->mark(K_GATEUP);
@@ -380,6 +534,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.W = lw.wdown; a.x = s->hbuf.as<float>() + (size_t)r0 * F; a.N = d; a.K = F; a.rows = rg;
             a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
             a.waves = m->tune[3]; a.rows_per_chunk = m->tune_rows[3];
+            a.bias = lw.b_down;
             T3MI_SET_STAMPS(a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
             r0 += rg;
@@ -407,19 +562,22 @@ struct GemmCtx {
 int run_layers_gemm(t3mi_model* m, Session* s, const GemmCtx& c, StepTimer* tm) {
     const int d = m->d, F = m->F, H = m->H;
     const int abf = m->wdtype == T3MI_W_BF16 ? 1 : 0;
+    const bool turbo = m->variant == T3MI_VARIANT_TURBO;
     const size_t layer_kv = (size_t)s->rows * H * s->max_len * 64;
     hipStream_t st = m->stream;
     for (int l = 0; l < m->n_layers; ++l) {
         const LayerW& lw = m->layers[l];
         float* kc = s->kc.as<float>() + layer_kv * l;
         float* vc = s->vc.as<float>() + layer_kv * l;
-        HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln1, m->eps, c.xn, c.M, d, abf, st));
+        if (turbo) HIPCHK(t3k::launch_layernorm_rows(c.x, lw.ln1, lw.ln1_b, m->eps, c.xn, c.M, d, abf, st));
+        else HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln1, m->eps, c.xn, c.M, d, abf, st));
         {
             t3k::GemmArgs a;
             a.W = lw.wqkv; a.A = c.xn; a.M = c.M; a.N = 3 * d; a.K = d;
             a.posmap = c.posmap; a.rowmap = c.rowmap;
             a.rope_cos = m->rope_cos.as<float>(); a.rope_sin = m->rope_sin.as<float>();
             a.q = c.q; a.kcache = kc; a.vcache = vc; a.n_heads = H; a.max_len = s->max_len;
+            if (turbo) { a.bias = lw.b_qkv; a.rope = 0; }
             HIPCHK(t3k::launch_gemm(a, t3k::EPI_ROPE_KV, m->wdtype, st));
         }
         if (tm) tm->mark(K_QKV);
@@ -436,21 +594,23 @@ int run_layers_gemm(t3mi_model* m, Session* s, const GemmCtx& c, StepTimer* tm) 
         {
             t3k::GemmArgs a;
             a.W = lw.wo; a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
-            a.y = c.x; a.resid = c.x; a.ldy = d;
+            a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_o;
             HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, m->wdtype, st));
         }
         if (tm) tm->mark(K_OPROJ);
-        HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln2, m->eps, c.xn, c.M, d, abf, st));
+        if (turbo) HIPCHK(t3k::launch_layernorm_rows(c.x, lw.ln2, lw.ln2_b, m->eps, c.xn, c.M, d, abf, st));
+        else HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln2, m->eps, c.xn, c.M, d, abf, st));
         {
             t3k::GemmArgs a;
-            a.W = lw.wgu; a.A = c.xn; a.M = c.M; a.N = 2 * F; a.K = d; a.yact = c.hact;
-            HIPCHK(t3k::launch_gemm(a, t3k::EPI_SWIGLU, m->wdtype, st));
+            a.W = lw.wgu; a.A = c.xn; a.M = c.M; a.N = turbo ? F : 2 * F; a.K = d; a.yact = c.hact;
+            a.bias = lw.b_fc;
+            HIPCHK(t3k::launch_gemm(a, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, m->wdtype, st));
         }
         if (tm) tm->mark(K_GATEUP);
         {
             t3k::GemmArgs a;
             a.W = lw.wdown; a.A = c.hact; a.M = c.M; a.N = d; a.K = F;
-            a.y = c.x; a.resid = c.x; a.ldy = d;
+            a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_down;
             HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, m->wdtype, st));
         }
         if (tm) tm->mark(K_DOWN);
@@ -470,12 +630,16 @@ GemmCtx decode_ctx(Session* s) {
 
 int run_head(t3mi_model* m, Session* s, StepTimer* tm) {
     const int d = m->d;
+    const bool turbo = m->variant == T3MI_VARIANT_TURBO;
     if (s->gemm_mode) {
         const int abf = m->wdtype == T3MI_W_BF16 ? 1 : 0;
-        HIPCHK(t3k::launch_rmsnorm_rows(s->x.as<float>(), m->norm_w, m->eps, s->xn.p, s->rows, d, abf, m->stream));
+        if (turbo)
+            HIPCHK(t3k::launch_layernorm_rows(s->x.as<float>(), m->norm_w, m->norm_b, m->eps, s->xn.p, s->rows, d, abf,
+                                              m->stream));
+        else HIPCHK(t3k::launch_rmsnorm_rows(s->x.as<float>(), m->norm_w, m->eps, s->xn.p, s->rows, d, abf, m->stream));
         t3k::GemmArgs a;
         a.W = m->head_w; a.A = s->xn.p; a.M = s->rows; a.N = m->V; a.K = d;
-        a.y = s->logits.as<float>(); a.ldy = m->V;
+        a.y = s->logits.as<float>(); a.ldy = m->V; a.bias = m->head_b;
         HIPCHK(t3k::launch_gemm(a, t3k::EPI_STORE, m->wdtype, m->stream));
         if (tm) tm->mark(K_HEAD);
         return T3MI_OK;
@@ -487,6 +651,7 @@ int run_head(t3mi_model* m, Session* s, StepTimer* tm) {
         a.N = m->V; a.K = d; a.rows = rg;
         a.y = s->logits.as<float>() + (size_t)r0 * m->V; a.ldy = m->V;
         a.waves = m->tune[4]; a.rows_per_chunk = m->tune_rows[4];
+        if (turbo) { a.layernorm = 1; a.bias = m->head_b_f; }   // ln_f + speech_head with bias (R/t3.R:1444)
         T3MI_SET_STAMPS(a);
         HIPCHK(t3k::launch_gemv(a, t3k::EPI_STORE, m->wdtype, m->stream));
         r0 += rg;
@@ -502,11 +667,13 @@ int run_sampler(t3mi_model* m, Session* s, StepTimer* tm) {
     a.cfg_w = p.cfg_weight; a.temperature = p.temperature; a.top_p = p.top_p; a.min_p = p.min_p;
     a.penalty = p.repetition_penalty; a.variant = p.sampler; a.top_k = p.top_k; a.stop_token = p.stop_token;
     a.mask_stop = p.mask_stop; a.max_new_tokens = p.max_new_tokens; a.seed = p.seed;
+    a.start_token = p.start_token;
     a.seen = s->seen.as<uint8_t>(); a.tokens = s->tokens.as<int>(); a.cap = s->cap;
     a.n_tokens = s->n_tokens.as<int>(); a.done = s->done.as<int>(); a.rowpos = s->rowpos.as<int>();
     a.s0 = s->s0_dev.as<int>();
     a.forced = s->n_forced > 0 ? s->forced.as<int>() : nullptr; a.n_forced = s->n_forced;
-    a.emb = m->emb.as<float>(); a.pos_emb = m->pos_emb.as<float>(); a.d = m->d; a.max_pos = m->max_pos;
+    a.emb = m->emb.as<float>(); a.d = m->d; a.max_pos = m->max_pos;
+    a.pos_emb = m->variant == T3MI_VARIANT_TURBO ? nullptr : m->pos_emb.as<float>();
     a.max_len = s->max_len; a.x = s->x.as<float>();
     a.rope_cos = m->rope_cos.as<float>(); a.rope_sin = m->rope_sin.as<float>(); a.rope_cur = s->rope_cur.as<float>();
     a.dist_ids = s->dist_ids.as<int>(); a.dist_probs = s->dist_probs.as<float>(); a.dist_n = s->dist_n.as<int>();
@@ -577,8 +744,8 @@ int t3mi_device_count(void) {
 int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model** out) {
     if (!path || !out) return fail(T3MI_ERR_ARG, "t3mi_open: null argument");
     *out = nullptr;
-    if (variant != T3MI_VARIANT_LLAMA)
-        return fail(T3MI_ERR_ARG, "t3mi_open: only T3MI_VARIANT_LLAMA is implemented in this build");
+    if (variant != T3MI_VARIANT_LLAMA && variant != T3MI_VARIANT_TURBO)
+        return fail(T3MI_ERR_ARG, "t3mi_open: variant must be T3MI_VARIANT_LLAMA or T3MI_VARIANT_TURBO");
     if (wdtype != T3MI_W_F32 && wdtype != T3MI_W_BF16) return fail(T3MI_ERR_ARG, "t3mi_open: bad wdtype");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -608,7 +775,7 @@ int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model*
     }
     HIPCHK(t3k::init_device());
     HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-    int rc = load_llama(m.get(), st);
+    int rc = variant == T3MI_VARIANT_TURBO ? load_turbo(m.get(), st) : load_llama(m.get(), st);
     if (rc) {
         (void)hipStreamDestroy(m->stream);
         return rc;
@@ -666,9 +833,17 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     if (p->cfg_weight > 0.f && rpu != 2)
         return fail(T3MI_ERR_ARG, "cfg_weight > 0 needs the cond/uncond row pair (rows = 2, R/t3.R:480-491)");
     if (p->max_new_tokens <= 0) return fail(T3MI_ERR_ARG, "max_new_tokens must be positive");
-    if (p->sampler != T3MI_SAMPLER_R && p->sampler != T3MI_SAMPLER_CPP)
-        return fail(T3MI_ERR_ARG, "sampler must be T3MI_SAMPLER_R or T3MI_SAMPLER_CPP for the Llama variant");
-    if (!(p->temperature > 0.f)) return fail(T3MI_ERR_ARG, "temperature must be > 0");
+    const bool turbo = m->variant == T3MI_VARIANT_TURBO;
+    if (turbo) {
+        // t3_inference_turbo: one row per utterance, no CFG, its own logit processors (R/t3.R:1578-1742)
+        if (p->sampler != T3MI_SAMPLER_TURBO) return fail(T3MI_ERR_ARG, "the Turbo variant needs sampler = T3MI_SAMPLER_TURBO");
+        if (rpu != 1 || p->cfg_weight > 0.f) return fail(T3MI_ERR_ARG, "the Turbo variant runs without CFG (rows = 1, cfg_weight = 0)");
+        if (p->start_token < 0 || p->start_token >= m->V) return fail(T3MI_ERR_ARG, "start_token outside the vocabulary");
+    } else {
+        if (p->sampler != T3MI_SAMPLER_R && p->sampler != T3MI_SAMPLER_CPP)
+            return fail(T3MI_ERR_ARG, "sampler must be T3MI_SAMPLER_R or T3MI_SAMPLER_CPP for the Llama variant");
+        if (!(p->temperature > 0.f)) return fail(T3MI_ERR_ARG, "temperature must be > 0");
+    }
     if (!(p->repetition_penalty > 0.f)) return fail(T3MI_ERR_ARG, "repetition_penalty must be > 0");
     if (p->stop_token < 0 || p->stop_token >= m->V) return fail(T3MI_ERR_ARG, "stop_token outside the vocabulary");
     HIPCHK(hipSetDevice(m->device));
@@ -696,6 +871,8 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         max_new = std::min(max_new, room);
     }
     if (max_new + 1 > m->max_pos) max_new = m->max_pos - 1;  // learned speech pos-emb rows (R/t3.R:349)
+    // Turbo samples one token from the prefill logits and then up to max_new_tokens more (R/t3.R:1614-1658)
+    if (turbo) max_new += 1;
     s->prm.max_new_tokens = max_new;
     s->cap = max_new;
     s->max_len = ((p->max_cache_len > 0 ? p->max_cache_len : max_s0 + max_new) + 7) & ~7;

@@ -19,7 +19,8 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["T3Model", "load_t3", "t3_inference", "t3_inference_cpp", "t3_inference_batch", "Session"]
+__all__ = ["T3Model", "load_t3", "load_t3_turbo", "t3_inference", "t3_inference_cpp", "t3_inference_batch",
+           "t3_inference_turbo", "t3_inference_turbo_batch", "Session"]
 
 _DT = {"f32": _lib.W_F32, "fp32": _lib.W_F32, "float32": _lib.W_F32, "bf16": _lib.W_BF16,
        "bfloat16": _lib.W_BF16}
@@ -39,6 +40,7 @@ class T3Model:
         _lib.check(self._lib.t3mi_get_info(self._h, C.byref(info)))
         self.info = info
         self.d_model, self.vocab, self.n_layers = info.d_model, info.vocab, info.n_layers
+        self.variant = int(variant)
         # R/t3.R:19-20 (overridable for reduced-vocabulary test checkpoints)
         self.start_speech_token, self.stop_speech_token = int(start_speech_token), int(stop_speech_token)
 
@@ -64,8 +66,13 @@ def load_t3(path: str, device: int = 0, dtype: str = "f32", **kw) -> T3Model:
     return T3Model(path, device, dtype, **kw)
 
 
+def load_t3_turbo(path: str, device: int = 0, dtype: str = "f32", **kw) -> T3Model:
+    """Turbo T3 (GPT-2 backbone): t3_model_turbo + load_t3_turbo_weights, R/t3.R:1347-1557."""
+    return T3Model(path, device, dtype, variant=_lib.VARIANT_TURBO, **kw)
+
+
 def _params(model: T3Model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
-            sampler, max_cache_len=0, seed=0, mask_stop=False) -> _lib.Params:
+            sampler, max_cache_len=0, seed=0, mask_stop=False, top_k=0) -> _lib.Params:
     p = _lib.Params()
     model._lib.t3mi_default_params(C.byref(p))
     p.max_new_tokens = int(max_new_tokens)
@@ -77,6 +84,7 @@ def _params(model: T3Model, max_new_tokens, temperature, cfg_weight, top_p, min_
     p.start_token = int(model.start_speech_token)
     p.stop_token = int(model.stop_speech_token)
     p.sampler = int(sampler)
+    p.top_k = int(top_k)
     p.max_cache_len = int(max_cache_len)
     p.mask_stop = 1 if mask_stop else 0
     p.seed = int(seed)
@@ -156,6 +164,42 @@ def t3_inference_batch(model: T3Model, embeds_list: Sequence, max_new_tokens: in
     return [out[u, : n_out[u]].astype(np.int64) for u in range(n_utt)]
 
 
+def t3_inference_turbo_batch(model: T3Model, embeds_list: Sequence, max_new_tokens: int = 1000,
+                             temperature: float = 0.8, top_k: int = 1000, top_p: float = 0.95,
+                             repetition_penalty: float = 1.2, seed: int = 0, mask_stop: bool = False,
+                             keep_stop: bool = False) -> List[np.ndarray]:
+    """Independent Turbo utterances decoded together; per-utterance semantics of t3_inference_turbo."""
+    if model.variant != _lib.VARIANT_TURBO:
+        raise ValueError("t3_inference_turbo needs a model opened with load_t3_turbo")
+    es = [_as_embeds(model, e, 0.0) for e in embeds_list]
+    n_utt = len(es)
+    p = _params(model, max_new_tokens, temperature, 0.0, top_p, 0.0, repetition_penalty,
+                _lib.SAMPLER_TURBO, 0, seed, mask_stop, top_k)
+    ptrs = (C.c_void_p * n_utt)(*[e.ctypes.data for e in es])
+    s0 = (C.c_int32 * n_utt)(*[e.shape[1] for e in es])
+    cap = int(max_new_tokens) + 1            # first token from the prefill + max_new_tokens more (R/t3.R:1614-1658)
+    out = np.zeros((n_utt, cap), dtype=np.int32)
+    n_out = (C.c_int32 * n_utt)()
+    _lib.check(model._lib.t3mi_generate_batch(
+        model._h, n_utt, 1, ptrs, s0, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_int32)), cap, n_out))
+    res = []
+    for u in range(n_utt):
+        t = out[u, : n_out[u]].astype(np.int64)
+        if not keep_stop and t.size and t[-1] == model.stop_speech_token:
+            t = t[:-1]                       # R/t3.R:1667-1671
+        res.append(t)
+    return res
+
+
+def t3_inference_turbo(model: T3Model, embeds, max_new_tokens: int = 1000, temperature: float = 0.8,
+                       top_k: int = 1000, top_p: float = 0.95, repetition_penalty: float = 1.2,
+                       seed: int = 0) -> np.ndarray:
+    """R/t3.R:1578-1677 after prepare_input_embeds ([1, S0, d] prompt rows): no CFG, no position term on the
+    generated tokens, top-k / top-p logit processors; a trailing stop token is removed (:1667-1671)."""
+    return t3_inference_turbo_batch(model, [embeds], max_new_tokens, temperature, top_k, top_p,
+                                    repetition_penalty, seed)[0]
+
+
 class Session:
     """The decode loop in pieces (t3mi_session_*): prefill once, then enqueue steps.
     Used by bench.py (timed region = decode steps only) and by the parity tests
@@ -165,11 +209,14 @@ class Session:
                  temperature: float = 0.8, cfg_weight: float = 0.5, top_p: float = 0.95,
                  min_p: float = 0.05, repetition_penalty: float = 1.2, sampler: int = _lib.SAMPLER_R,
                  max_cache_len: int = 0, seed: int = 0, mask_stop: bool = False,
-                 forced: Optional[np.ndarray] = None, device_ptrs: Optional[Sequence[Tuple[int, int]]] = None):
+                 forced: Optional[np.ndarray] = None, device_ptrs: Optional[Sequence[Tuple[int, int]]] = None,
+                 top_k: int = 0):
         self.model = model
         L = model._lib
+        if model.variant == _lib.VARIANT_TURBO:
+            sampler, cfg_weight, min_p = _lib.SAMPLER_TURBO, 0.0, 0.0
         p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
-                    sampler, max_cache_len, seed, mask_stop)
+                    sampler, max_cache_len, seed, mask_stop, top_k)
         if device_ptrs is not None:
             # [(device_address, s0)] of prompts already resident in HBM, each [rpu, s0, d] float32
             self.n_utt = len(device_ptrs)
@@ -186,7 +233,7 @@ class Session:
             s0 = (C.c_int32 * self.n_utt)(*[e.shape[1] for e in es])
             on_dev = 0
         _lib.check(L.t3mi_session_begin(model._h, self.n_utt, self.rpu, ptrs, s0, C.byref(p), on_dev))
-        self.max_new_tokens = int(max_new_tokens)
+        self.max_new_tokens = int(max_new_tokens) + (1 if model.variant == _lib.VARIANT_TURBO else 0)
         if forced is not None:
             f = np.ascontiguousarray(forced, dtype=np.int32).reshape(self.n_utt, -1)
             _lib.check(L.t3mi_session_force(model._h, f.ctypes.data_as(C.POINTER(C.c_int32)), f.shape[1]))

@@ -59,3 +59,13 @@ def draw_is_consistent(drawn: int, tail) -> bool:
 def rel_err(a: np.ndarray, b: np.ndarray) -> float:
     """max |a-b| / max |b|  (the 1e-3 fp32 bar of BASELINE.json is applied to this)."""
     return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / np.abs(b).max())
+
+
+def turbo_cfg(dims: synth.TurboDims) -> O.TurboConfig:
+    return O.TurboConfig(hidden_size=dims.hidden_size, n_head=dims.n_head, n_layer=dims.n_layer,
+                         speech_vocab=dims.speech_vocab, start_speech_token=dims.start_speech_token,
+                         stop_speech_token=dims.stop_speech_token)
+
+
+def turbo_oracle(dims: synth.TurboDims, seed: int = 4321, head_scale: float = 1.0) -> O.GPT2Oracle:
+    return O.GPT2Oracle(synth.synth_turbo_weights(dims, seed, head_scale), turbo_cfg(dims))
