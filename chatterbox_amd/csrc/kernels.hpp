@@ -26,6 +26,19 @@ enum Prologue : int {
 #define T3K_STAMP_WAVES 8192
 #endif
 
+// One weight-streaming launch of the decode step as the L2 prefetcher sees it (weight_prefetch_kernel):
+// which rows of W the blocks of each XCD will stream.  Filled by launch_gemv (geom_out).
+struct PfItem {
+    const void* W = nullptr;      // nullptr: a launch that streams no weights (sampler, attention)
+    unsigned row_bytes = 0;       // K * sizeof(weight element)
+    int N = 0;                    // rows of W
+    int kind = 0;                 // chunk -> row map: 0 linear, 1 rotate_half pairs (QKV), 2 gate/up pairs
+    int rows = 1;                 // rows per chunk
+    int ngrp = 1;                 // chunks a block handles per pass
+    int grid = 1;                 // blocks of the launch
+    int n_chunks = 0;
+};
+
 struct GemvArgs {
     const void* W = nullptr;      // [N, K] row-major (row = output feature), fp32 or bf16
     const float* x = nullptr;     // [rows, K]
@@ -52,6 +65,8 @@ struct GemvArgs {
     int n_split_max = 0, keys_per_split = 0;
     int waves = 0;                // waves per block (0 = default 4)
     int rows_per_chunk = 0;       // output features per wave-chunk (0 = kernel default)
+    int* progress = nullptr;      // device launch counter of the decode chain (block 0 adds 1), or nullptr
+    PfItem* geom_out = nullptr;   // host: receives this launch's geometry for the prefetch plan
 #ifdef T3K_STAMPS
     unsigned long long* stamps = nullptr;  // diagnostic build only: [T3K_STAMP_WAVES][T3K_STAMP_SLOTS] of this launch
 #endif
@@ -68,6 +83,7 @@ struct AttnArgs {
     float* pacc = nullptr;
     int rows = 0, n_heads = 0, max_len = 0;
     int n_split_max = 0, keys_per_split = 64;
+    int* progress = nullptr;
 #ifdef T3K_STAMPS
     unsigned long long* stamps = nullptr;
 #endif
@@ -134,6 +150,7 @@ struct SamplerArgs {
     int* dist_n = nullptr;
     int* drawn = nullptr;         // [n_utt] token drawn before teacher forcing (debug)
     int dist_cap = 0;
+    int* progress = nullptr;
 };
 
 size_t sampler_lds_bytes(int V);
@@ -153,6 +170,16 @@ hipError_t launch_rmsnorm_rows(const float* x, const float* w, float eps, void* 
 hipError_t launch_attn_merge(const float* pm, const float* pl, const float* pacc, const int* posmap, void* out, int M,
                              int H, int n_split_max, int kps, int act_bf16, hipStream_t s);
 hipError_t launch_gather_rows(const float* const* src_rows, float* x, int M, int d, hipStream_t s);
+// ---- L2 weight prefetcher (runs beside the decode chain on its own stream; performance hint only) ----
+// state: int[32] device words: [0] progress counter, [8..15] per-XCD tickets, [16..23] slot_of_xcc
+//        [24] diagnostic switch, [32..1055] XCD of block 0 of the last 1024 chain launches
+constexpr int kPfProgress = 0, kPfTickets = 8, kPfSlots = 16, kPfLogOn = 24, kPfXccLog = 32, kPfWords = 32 + 1024;
+// records the hardware XCD id of every block of a 256-block launch into out[256] (placement census)
+hipError_t launch_xcc_census(int* out, hipStream_t s);
+// prefetches the weights of plan items [0, n_items) of the step whose first launch is number `base`
+hipError_t launch_weight_prefetch(const PfItem* plan_dev, int n_items, int* state, int base, int lookahead,
+                                  int blocks, int depth, int max_polls, float* sink, hipStream_t s,
+                                  long long* dbg = nullptr);
 // fp32 -> bf16 (round to nearest even) on device, n elements
 hipError_t launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 

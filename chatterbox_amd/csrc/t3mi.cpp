@@ -85,6 +85,12 @@ struct Session {
     DevBuf kc, vc, x, qbuf, pm, pl, pacc, hbuf, logits, rope_cur, rowpos, start, emb_rows, emb_data, seen, tokens, n_tokens,
         done, s0_dev, forced, dist_ids, dist_probs, dist_n, drawn;
     int n_forced = 0;
+    // L2 weight prefetcher (see weight_prefetch_kernel): the step's weight-streaming launches in order
+    bool pf_on = false, plan_ready = false, plan_collect = false;
+    std::vector<t3k::PfItem> plan;
+    DevBuf plan_dev, pf_dbg;   // pf_dbg: T3MI_PF_DEBUG=1 diagnostic (per item: counter lead and clock at start / end)
+    long long bumps = 0;   // host mirror of the device launch counter
+    int step_bumps = 0;    // launches of one decode step
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     bool graph_tried = false;
@@ -112,6 +118,10 @@ struct t3mi_model {
     int64_t weight_bytes = 0;
     std::unique_ptr<Session> sess;
     bool use_graph = true;
+    hipStream_t pf_stream = nullptr;   // the prefetcher runs beside the decode chain
+    DevBuf pf_state, pf_sink;
+    bool pf_ok = false;                // placement census passed and T3MI_PREFETCH != 0
+    int pf_lookahead = 2, pf_blocks = 64, pf_depth = 2, pf_max_polls = 4000;
     int tune[5] = {8, 4, 8, 8, 8};  // waves per block: qkv, o_proj, gate_up, down, head (T3MI_WAVES=a,b,c,d,e)
     int tune_rows[5] = {2, 1, 2, 2, 2};  // output rows per wave-chunk, same order (T3MI_ROWS=a,b,c,d,e)
 };
@@ -439,6 +449,16 @@ unsigned long long* next_stamps() {
 #define T3MI_SET_STAMPS(a) do { } while (0)
 #endif
 
+// chain launch bookkeeping for the prefetcher: counter pointer into the kernel, geometry into the plan
+inline int* pf_progress(t3mi_model* m, Session* s) {
+    if (!s->pf_on) return nullptr;
+    s->bumps += 1;
+    return m->pf_state.as<int>() + t3k::kPfProgress;
+}
+inline void pf_note(Session* s, const t3k::PfItem& it) {
+    if (s->pf_on && s->plan_collect) s->plan.push_back(it);
+}
+
 struct StepTimer {  // optional per-launch events for t3mi_session_profile_step
     std::vector<hipEvent_t> ev;
     std::vector<int> kind;
@@ -479,8 +499,11 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.n_heads = H; a.max_len = s->max_len;
             a.waves = m->tune[0]; a.rows_per_chunk = m->tune_rows[0];
             if (turbo) { a.layernorm = 1; a.bias = lw.b_qkv_f; a.rope = 0; }
+            t3k::PfItem geom;
+            a.progress = pf_progress(m, s); a.geom_out = &geom;
             T3MI_SET_STAMPS(a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_ROPE_KV, m->wdtype, m->stream));
+            pf_note(s, geom);
             r0 += rg;
         }
         if (tm) tm->mark(K_QKV);
@@ -491,8 +514,10 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.pm = s->pm.as<float>(); a.pl = s->pl.as<float>(); a.pacc = s->pacc.as<float>();
             a.rows = s->rows; a.n_heads = H; a.max_len = s->max_len;
             a.n_split_max = s->n_split; a.keys_per_split = s->kps;
+            a.progress = pf_progress(m, s);
             T3MI_SET_STAMPS(a);
             HIPCHK(t3k::launch_attn_decode(a, m->stream));
+            pf_note(s, t3k::PfItem{});
         }
         if (tm) tm->mark(K_ATTN);
         // K3: softmax-merge + o_proj + residual
@@ -508,8 +533,11 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
             a.waves = m->tune[1]; a.rows_per_chunk = m->tune_rows[1];
             a.bias = lw.b_o;
+            t3k::PfItem geom;
+            a.progress = pf_progress(m, s); a.geom_out = &geom;
             T3MI_SET_STAMPS(a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
+            pf_note(s, geom);
             r0 += rg;
         }
         if (tm) tm->mark(K_OPROJ);
@@ -522,8 +550,11 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.y = s->hbuf.as<float>() + (size_t)r0 * F; a.ldy = F;
             a.waves = m->tune[2]; a.rows_per_chunk = m->tune_rows[2];
             if (turbo) { a.layernorm = 1; a.bias = lw.b_fc_f; }   // LayerNorm + c_fc + gelu_tanh (R/t3.R:1303-1304)
+            t3k::PfItem geom;
+            a.progress = pf_progress(m, s); a.geom_out = &geom;
             T3MI_SET_STAMPS(a);
             HIPCHK(t3k::launch_gemv(a, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, m->wdtype, m->stream));
+            pf_note(s, geom);
             r0 += rg;
         }
         if (tm) tm->mark(K_GATEUP);
@@ -535,8 +566,11 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
             a.waves = m->tune[3]; a.rows_per_chunk = m->tune_rows[3];
             a.bias = lw.b_down;
+            t3k::PfItem geom;
+            a.progress = pf_progress(m, s); a.geom_out = &geom;
             T3MI_SET_STAMPS(a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
+            pf_note(s, geom);
             r0 += rg;
         }
         if (tm) tm->mark(K_DOWN);
@@ -652,8 +686,11 @@ int run_head(t3mi_model* m, Session* s, StepTimer* tm) {
         a.y = s->logits.as<float>() + (size_t)r0 * m->V; a.ldy = m->V;
         a.waves = m->tune[4]; a.rows_per_chunk = m->tune_rows[4];
         if (turbo) { a.layernorm = 1; a.bias = m->head_b_f; }   // ln_f + speech_head with bias (R/t3.R:1444)
+        t3k::PfItem geom;
+        a.progress = pf_progress(m, s); a.geom_out = &geom;
         T3MI_SET_STAMPS(a);
         HIPCHK(t3k::launch_gemv(a, t3k::EPI_STORE, m->wdtype, m->stream));
+        pf_note(s, geom);
         r0 += rg;
     }
     if (tm) tm->mark(K_HEAD);
@@ -679,7 +716,9 @@ int run_sampler(t3mi_model* m, Session* s, StepTimer* tm) {
     a.dist_ids = s->dist_ids.as<int>(); a.dist_probs = s->dist_probs.as<float>(); a.dist_n = s->dist_n.as<int>();
     a.drawn = s->drawn.as<int>();
     a.dist_cap = m->V;
+    a.progress = pf_progress(m, s);
     HIPCHK(t3k::launch_sampler(a, m->stream));
+    pf_note(s, t3k::PfItem{});
     if (tm) tm->mark(K_SAMPLER);
     return T3MI_OK;
 }
@@ -693,10 +732,38 @@ int run_decode_step(t3mi_model* m, Session* s, StepTimer* tm) {
     return run_head(m, s, tm);
 }
 
+int upload_plan(t3mi_model* m, Session* s) {
+    if (!s->pf_on || s->plan_ready || s->plan.empty()) return T3MI_OK;
+    HIPCHK(s->plan_dev.alloc(s->plan.size() * sizeof(t3k::PfItem)));
+    HIPCHK(hipMemcpy(s->plan_dev.p, s->plan.data(), s->plan.size() * sizeof(t3k::PfItem), hipMemcpyHostToDevice));
+    s->plan_ready = true;
+    if (const char* d = std::getenv("T3MI_PF_DEBUG"))
+        if (d[0] == '1') {
+            HIPCHK(s->pf_dbg.alloc(s->plan.size() * 4 * 8));
+            HIPCHK(hipMemset(s->pf_dbg.p, 0, s->plan.size() * 4 * 8));
+        }
+    return T3MI_OK;
+}
+
+// enqueue the prefetcher of the step whose first launch will be number s->bumps + 1
+int launch_prefetch(t3mi_model* m, Session* s) {
+    if (!s->pf_on || !s->plan_ready) return T3MI_OK;
+    HIPCHK(t3k::launch_weight_prefetch(s->plan_dev.as<t3k::PfItem>(), (int)s->plan.size(), m->pf_state.as<int>(),
+                                       (int)s->bumps, m->pf_lookahead, m->pf_blocks, m->pf_depth, m->pf_max_polls,
+                                       m->pf_sink.as<float>(), m->pf_stream, s->pf_dbg.as<long long>()));
+    return T3MI_OK;
+}
+
 int build_graph(t3mi_model* m, Session* s) {
     s->graph_tried = true;
+    const long long bumps0 = s->bumps;
+    s->plan_collect = s->pf_on && !s->plan_ready;
+    if (s->plan_collect) s->plan.clear();
     HIPCHK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
     int rc = run_decode_step(m, s, nullptr);
+    s->plan_collect = false;
+    s->step_bumps = (int)(s->bumps - bumps0);
+    s->bumps = bumps0;   // captured, not executed
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(m->stream, &g);
     if (rc) {
@@ -706,7 +773,7 @@ int build_graph(t3mi_model* m, Session* s) {
     if (e != hipSuccess) return fail(T3MI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
     s->graph = g;
     HIPCHK(hipGraphInstantiate(&s->gexec, g, nullptr, nullptr, 0));
-    return T3MI_OK;
+    return upload_plan(m, s);
 }
 
 int need_session(t3mi_model* m) {
@@ -775,13 +842,55 @@ int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model*
     }
     HIPCHK(t3k::init_device());
     HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&m->pf_stream, hipStreamNonBlocking));
+    {
+        // block placement census: the prefetcher needs "blocks with blockIdx % 8 == k run on hardware XCD q"
+        HIPCHK(m->pf_state.alloc(t3k::kPfWords * 4));
+        HIPCHK(m->pf_sink.alloc(1024 * 4));
+        DevBuf cen;
+        HIPCHK(cen.alloc(256 * 4));
+        HIPCHK(t3k::launch_xcc_census(cen.as<int>(), m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        int xcc[256];
+        std::vector<int> stv(t3k::kPfWords, 0);
+        int* st = stv.data();
+        HIPCHK(hipMemcpy(xcc, cen.p, sizeof(xcc), hipMemcpyDeviceToHost));
+        if (const char* d = std::getenv("T3MI_PF_DEBUG")) st[t3k::kPfLogOn] = d[0] == '1';
+        for (int q = 0; q < 8; ++q) st[t3k::kPfSlots + q] = -1;
+        bool ok = true;
+        int cnt[8] = {0};
+        for (int b = 0; b < 256 && ok; ++b) {
+            const int q = xcc[b];
+            if (q < 0 || q > 7) { ok = false; break; }
+            int& slot = st[t3k::kPfSlots + q];
+            if (slot < 0) slot = b % 8;
+            else if (slot != b % 8) ok = false;
+            cnt[q] += 1;
+        }
+        for (int q = 0; q < 8; ++q) ok = ok && cnt[q] == 32;
+        const char* pe = std::getenv("T3MI_PREFETCH");
+        m->pf_ok = ok && pe && pe[0] == '1';   // experiment, off by default: measured slower
+        HIPCHK(hipMemcpy(m->pf_state.p, st, stv.size() * 4, hipMemcpyHostToDevice));
+        if (const char* v = std::getenv("T3MI_PF_LOOKAHEAD")) m->pf_lookahead = std::max(1, std::atoi(v));
+        if (const char* v = std::getenv("T3MI_PF_MODE")) m->pf_max_polls |= (std::atoi(v) & 3) << 24;
+        if (const char* v = std::getenv("T3MI_PF_DEPTH")) {
+            const int dp = std::atoi(v);
+            if (dp == 1 || dp == 2 || dp == 4 || dp == 8) m->pf_depth = dp;
+        }
+        if (const char* v = std::getenv("T3MI_PF_BLOCKS")) {
+            const int nb = std::atoi(v);
+            if (nb >= 8 && nb <= 1024 && nb % 8 == 0) m->pf_blocks = nb;
+        }
+    }
     int rc = variant == T3MI_VARIANT_TURBO ? load_turbo(m.get(), st) : load_llama(m.get(), st);
     if (rc) {
         (void)hipStreamDestroy(m->stream);
+        (void)hipStreamDestroy(m->pf_stream);
         return rc;
     }
     if (t3k::sampler_lds_bytes(m->V) > 160 * 1024 || m->V > 16384) {
         (void)hipStreamDestroy(m->stream);
+        (void)hipStreamDestroy(m->pf_stream);
         return fail(T3MI_ERR_IO, "vocabulary too large for the single-workgroup sampler");
     }
     HIPCHK(hipDeviceSynchronize());
@@ -793,8 +902,10 @@ int t3mi_close(t3mi_model* m) {
     if (!m) return T3MI_OK;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->pf_stream) (void)hipStreamSynchronize(m->pf_stream);
     m->sess.reset();
     if (m->stream) (void)hipStreamDestroy(m->stream);
+    if (m->pf_stream) (void)hipStreamDestroy(m->pf_stream);
     delete m;
     return T3MI_OK;
 }
@@ -821,6 +932,21 @@ int t3mi_session_end(t3mi_model* m) {
     if (!m) return fail(T3MI_ERR_ARG, "null model handle");
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->pf_stream) (void)hipStreamSynchronize(m->pf_stream);
+    if (m->sess && m->sess->pf_dbg.p) {
+        std::vector<int> lg(1024);
+        if (hipMemcpy(lg.data(), m->pf_state.as<int>() + t3k::kPfXccLog, 4096, hipMemcpyDeviceToHost) == hipSuccess) {
+            std::fprintf(stderr, "xcd of block 0, last launches:");
+            const long long n = m->sess->bumps;
+            for (long long i = std::max(0LL, n - 160); i < n; ++i) std::fprintf(stderr, " %d", lg[i & 1023]);
+            std::fprintf(stderr, "\n");
+        }
+        std::vector<long long> h(m->sess->plan.size() * 4);
+        if (hipMemcpy(h.data(), m->sess->pf_dbg.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            for (size_t i = 0; i < m->sess->plan.size() && i < 24; ++i)
+                std::fprintf(stderr, "pf item %2zu: lead at start %lld, at end %lld, t_start %.2f us, busy %.2f us\n", i, -h[4 * i],
+                             -h[4 * i + 2], (double)(h[4 * i + 1] - h[1]) * 0.01, (double)(h[4 * i + 3] - h[4 * i + 1]) * 0.01);
+    }
     m->sess.reset();
     return T3MI_OK;
 }
@@ -901,6 +1027,8 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         HIPCHK(s->attn_out.alloc(rows * d * as));
         HIPCHK(s->hact.alloc(rows * F * as));
     }
+    s->pf_on = m->pf_ok && !s->gemm_mode && rows <= 4;
+    if (s->pf_on) HIPCHK(hipMemsetAsync(m->pf_state.as<int>() + t3k::kPfProgress, 0, 4, m->stream));
     HIPCHK(s->logits.alloc(rows * V * 4));
     HIPCHK(s->rowpos.alloc(rows * 4));
     HIPCHK(s->rope_cur.alloc(rows * 128 * 4));
@@ -1067,8 +1195,18 @@ int t3mi_session_decode(t3mi_model* m, int n_steps) {
         if ((rc = build_graph(m, s))) return rc;
     }
     for (int i = 0; i < n_steps; ++i) {
-        if (s->gexec) HIPCHK(hipGraphLaunch(s->gexec, m->stream));
-        else if ((rc = run_decode_step(m, s, nullptr))) return rc;
+        if ((rc = launch_prefetch(m, s))) return rc;
+        if (s->gexec) {
+            HIPCHK(hipGraphLaunch(s->gexec, m->stream));
+            s->bumps += s->step_bumps;
+        } else {
+            s->plan_collect = s->pf_on && !s->plan_ready;
+            if (s->plan_collect) s->plan.clear();
+            rc = run_decode_step(m, s, nullptr);
+            s->plan_collect = false;
+            if (rc) return rc;
+            if ((rc = upload_plan(m, s))) return rc;
+        }
     }
     return T3MI_OK;
 }
@@ -1184,6 +1322,7 @@ int t3mi_session_profile_step(t3mi_model* m, t3mi_kstat* stats, int cap, int* n_
     tm.s = m->stream;
     tm.on = true;
     tm.mark(-1);
+    if (!s->plan_collect) (void)launch_prefetch(m, s);
     rc = run_decode_step(m, s, &tm);
     if (!rc) {
         hipError_t e = hipStreamSynchronize(m->stream);

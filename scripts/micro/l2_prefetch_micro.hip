@@ -1,0 +1,146 @@
+// Micro-benchmark: does an L2 prefetch issued by kernel N survive the kernel boundary so that kernel N+1's
+// weight stream hits its XCD's L2?  And how long does the first touch of a small activation vector take at
+// kernel start when the weights come from HBM / Infinity Cache / L2?
+// Build: hipcc -O3 --offload-arch=gfx950 l2_prefetch_micro.hip -o l2_prefetch_micro
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("ERR %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+constexpr int kWG = 256, kThreads = 512;
+
+// read-everything flush: evicts L2 and the 256 MiB Infinity Cache
+__global__ void k_flush(const float4* __restrict__ buf, size_t n4, float* sink) {
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = buf[i];
+        s += v.x + v.y + v.z + v.w;
+    }
+    if (s == 123.456f) sink[0] = s;
+}
+
+// previous kernel of the chain: writes x (every workgroup a slice) and optionally prefetches, one dword per 128-B
+// line, the slice that workgroup (b + shift) % 256 of the next kernel will stream
+__global__ __launch_bounds__(kThreads) void k_prev(float* __restrict__ x, int xn, const float* __restrict__ W, size_t slice_floats,
+                                                   int shift, int do_pf, float* sink, float xval) {
+    const int b = blockIdx.x;
+    for (int i = b * kThreads + threadIdx.x; i < xn; i += kWG * kThreads) x[i] = xval + (float)i;
+    if (do_pf) {
+        const int tb = (b + shift) % kWG;
+        const float* base = W + (size_t)tb * slice_floats;
+        float s = 0.f;
+        for (size_t l = threadIdx.x; l * 32 < slice_floats; l += kThreads) s += base[l * 32];
+        if (s == 123.456f) sink[b] = s;
+    }
+}
+
+// the measured kernel: x first (2 float4 per thread = 16 KB per block ... only the first 8 KB are distinct), then NV
+// float4 of weights per thread, all in flight at once; stamps: start, x landed, all landed
+template <int NV, bool NT>
+__global__ __launch_bounds__(kThreads) void k_read(const float* __restrict__ x, const float* __restrict__ W, size_t slice_floats,
+                                                   float* __restrict__ y, unsigned long long* __restrict__ stamps) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    const float4 xv = *reinterpret_cast<const float4*>(x + (tid & 511) * 4);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* wp = reinterpret_cast<const f4*>(W + (size_t)b * slice_floats);
+    f4 w[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if (NT) w[j] = __builtin_nontemporal_load(wp + j * kThreads + tid);
+        else w[j] = wp[j * kThreads + tid];
+    }
+    float s = xv.x + xv.y + xv.z + xv.w;
+    asm volatile("" : "+v"(s));
+    const unsigned long long t1 = wall_clock64();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += w[j].x * xv.x + w[j].y * xv.y + w[j].z * xv.z + w[j].w * xv.w;
+    asm volatile("" : "+v"(s));
+    const unsigned long long t2 = wall_clock64();
+    y[b * kThreads + tid] = s;
+    if ((tid & 63) == 0) {
+        const int w = b * (kThreads / 64) + (tid >> 6);
+        stamps[w * 3 + 0] = t0;
+        stamps[w * 3 + 1] = t1;
+        stamps[w * 3 + 2] = t2;
+    }
+}
+
+struct Res { double x_us, all_us, span_us; };
+
+int main() {
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    const size_t FB = 1ull << 30;
+    float *flushbuf, *W, *x, *y, *sink;
+    unsigned long long* stamps;
+    CK(hipMalloc(&flushbuf, FB));
+    CK(hipMalloc(&W, 256ull << 20));
+    CK(hipMalloc(&x, 1 << 20));
+    CK(hipMalloc(&y, 4 << 20));
+    CK(hipMalloc(&sink, 1 << 20));
+    const int n_w = kWG * kThreads / 64;
+    CK(hipMalloc(&stamps, (size_t)n_w * 3 * 8));
+    CK(hipMemset(flushbuf, 0, FB));
+    CK(hipMemset(W, 0, 256ull << 20));
+    CK(hipMemset(x, 0, 1 << 20));
+    std::vector<unsigned long long> h((size_t)n_w * 3);
+
+    auto collect = [&](Res& r) -> int {
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0min = ~0ull, t2max = 0;
+        std::vector<double> dx, da;
+        for (int w = 0; w < n_w; ++w) {
+            t0min = std::min(t0min, h[w * 3]);
+            t2max = std::max(t2max, h[w * 3 + 2]);
+            dx.push_back((double)(h[w * 3 + 1] - h[w * 3]) * 0.01);
+            da.push_back((double)(h[w * 3 + 2] - h[w * 3]) * 0.01);
+        }
+        std::sort(dx.begin(), dx.end());
+        std::sort(da.begin(), da.end());
+        r.x_us = dx[dx.size() / 2];
+        r.all_us = da[da.size() / 2];
+        r.span_us = (double)(t2max - t0min) * 0.01;
+        return 0;
+    };
+
+    auto run = [&](auto kread, int nv, const char* tag) -> int {
+        const size_t slice_floats = (size_t)nv * kThreads * 4;
+        const double mb = (double)slice_floats * 4 * kWG / 1e6;
+        const char* names[] = {"cold (flush, HBM)", "repeat (same launch again)", "prefetch by same-XCD block", "prefetch by block+1 (other XCD)",
+                               "prefetch + repeat every launch"};
+        for (int sc = 0; sc < 5; ++sc) {
+            std::vector<Res> rs;
+            for (int rep = 0; rep < 9; ++rep) {
+                Res r{};
+                if (sc != 1 && sc != 4) hipLaunchKernelGGL(k_flush, dim3(2048), dim3(256), 0, st, (const float4*)flushbuf, FB / 16, sink);
+                if (sc == 1) {
+                    hipLaunchKernelGGL(k_prev, dim3(kWG), dim3(kThreads), 0, st, x, 4096, W, slice_floats, 0, 0, sink, (float)rep);
+                    hipLaunchKernelGGL(kread, dim3(kWG), dim3(kThreads), 0, st, (const float*)x, (const float*)W, slice_floats, y, stamps);
+                }
+                const int pf = (sc >= 2) ? 1 : 0;
+                const int shift = (sc == 3) ? 1 : 0;
+                hipLaunchKernelGGL(k_prev, dim3(kWG), dim3(kThreads), 0, st, x, 4096, W, slice_floats, shift, pf, sink, (float)rep + 0.5f);
+                hipLaunchKernelGGL(kread, dim3(kWG), dim3(kThreads), 0, st, (const float*)x, (const float*)W, slice_floats, y, stamps);
+                if (collect(r)) return 1;
+                rs.push_back(r);
+            }
+            std::sort(rs.begin(), rs.end(), [](const Res& a, const Res& b) { return a.span_us < b.span_us; });
+            const Res& m = rs[rs.size() / 2];
+            printf("%-10s %6.1f MB  %-34s x landed %5.2f us   all landed %5.2f us   kernel span %5.2f us  (%.0f GB/s)\n", tag, mb, names[sc],
+                   m.x_us, m.all_us, m.span_us, mb / m.span_us * 1e-3 * 1e3);
+        }
+        return 0;
+    };
+    if (run(k_read<2, true>, 2, "nt")) return 1;       // 4.2 MB  (o_proj)
+    if (run(k_read<6, true>, 6, "nt")) return 1;       // 12.6 MB (qkv)
+    if (run(k_read<8, true>, 8, "nt")) return 1;       // 16.8 MB (down)
+    if (run(k_read<16, true>, 16, "nt")) return 1;     // 33.5 MB (gate_up)
+    if (run(k_read<6, false>, 6, "plain")) return 1;
+    if (run(k_read<16, false>, 16, "plain")) return 1;
+    printf("done\n");
+    return 0;
+}
