@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 namespace t3k {
 
@@ -298,6 +299,241 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* const* __
     for (int i = threadIdx.x; i < d; i += 256) x[(size_t)m * d + i] = s[i];
 }
 
+
+// ---- bf16 many-row GEMM, second generation ------------------------------------------------------------------
+// y[M,N] = A[M,K] * W[N,K]^T with bf16 operands, fp32 accumulate, for up to 128 rows per block.
+//
+// Block = 8 waves = 128 rows x 32 output features x one K range.  Wave w owns rows 16w..16w+15 and both 16-feature
+// sub-tiles, so it holds 2 accumulator tiles and reads its activation rows straight from global memory (L2), every
+// element exactly once per block and in whole 256-byte runs (lane (n, g) takes the 64 bytes k = g*32..g*32+31 of
+// its row per 128-k step: MFMA j of the step uses k = g*32 + 8j..8j+7 from both operands, a fixed permutation of
+// the dot product's terms).  The weight tile of a step (32 rows x 256 B, whole lines) goes global -> registers ->
+// LDS once per block and is shared by the 8 waves; a two-deep register ring keeps two steps of activations and one
+// of weights in flight.  The two sub-tiles hold PARTNER features of the fused epilogues (gate / up, rotate_half
+// i / i+32), so SwiGLU and RoPE finish in registers.  Compared with the first-generation kernel (16 features x K
+// split over the waves, every block re-reading all activation rows in 64-byte pieces) the L2 traffic for the
+// activations drops 2-4x and every request is a whole line: gate_up at 128 rows 31 us -> see DESIGN.md.
+// Residual GEMMs with few feature tiles (N = 1024) split K over blockIdx.z into fp32 partial slabs that
+// fold_partials_kernel sums in a fixed order (deterministic, no atomics).
+template <int EPI>
+__device__ __forceinline__ int tile32_feature(int t, int r32, int N) {
+    const int s = r32 >> 4, n = r32 & 15;
+    if (EPI == EPI_ROPE_KV) return (t >> 1) * kHeadDim + ((t & 1) << 4) + n + (s << 5);   // i = 16u + n, partner i + 32
+    if (EPI == EPI_SWIGLU) return s * (N >> 1) + 16 * t + n;                                // gate row, partner up row
+    return 32 * t + r32;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_rows_bf16_kernel(GemmArgs a) {
+    constexpr int KC = 128, LD = KC + 8;   // row stride 272 B: the 16 rows of a fragment read fall in distinct banks
+    constexpr int kRows = 160;             // 128 activation rows + 32 weight rows per step
+    extern __shared__ __attribute__((aligned(16))) uint16_t tl[];   // [2][kRows][LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = lane & 15, g = lane >> 4;
+    const int tile = blockIdx.x, m0 = blockIdx.y * 128, kz = blockIdx.z;
+    const int K = a.K;
+    const int S = (K / KC) / (int)gridDim.z;   // 128-k steps of this block
+    unsigned long long* dbg = a.dbg != nullptr && tid == 0
+                                  ? a.dbg + 4 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
+    if (dbg) dbg[0] = wall_clock64();
+    const int kbeg = kz * S * KC;
+    const uint16_t* Wp = static_cast<const uint16_t*>(a.W);
+    const uint16_t* Ap = static_cast<const uint16_t*>(a.A);
+
+    // staging: a step's tile is 160 rows x 256 B; thread t moves the 16 B piece t & 15 of rows (t >> 4) + 32 p,
+    // p = 0..4, so 16 consecutive lanes fetch one whole 256-byte run (rows 0..127 activations, 128..159 weights).
+    // Fetching the activation rows straight into MFMA fragments instead (16 rows x 64 B per instruction) asks L2 for
+    // every line four times: measured 3-4x slower at 128 rows.
+    const int srow = tid >> 4, spiece = tid & 15;
+    const uint16_t* src[5];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int r = m0 + p * 32 + srow;
+        r = r < a.M ? r : a.M - 1;
+        src[p] = Ap + (size_t)r * K + kbeg + spiece * 8;
+    }
+    {
+        int sf = tile32_feature<EPI>(tile, srow, a.N);
+        sf = sf < a.N ? sf : a.N - 1;
+        src[4] = Wp + (size_t)sf * K + kbeg + spiece * 8;
+    }
+    const int soff = srow * LD + spiece * 8;
+    const bool live = m0 + wave * 16 < a.M;
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // register rings: the weights come from HBM (2-3 us under load) and are requested kDW steps ahead, which for the
+    // decode shapes (K <= 1024 per block) is the block's whole weight slice at kernel start; the activation rows come
+    // from L2 and run kDA steps ahead.  A step of MFMAs is only ~0.1-0.2 us.
+    constexpr int kDW = 8, kDA = 3;
+    uint4 rw[kDW], ra[kDA][4];
+#pragma unroll
+    for (int q = 0; q < kDW; ++q) rw[q] = (q < S) ? *reinterpret_cast<const uint4*>(src[4] + (size_t)q * KC) : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < kDA; ++q)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            ra[q][p] = (q < S) ? *reinterpret_cast<const uint4*>(src[p] + (size_t)q * KC) : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(&tl[soff + p * 32 * LD]) = ra[0][p];
+    *reinterpret_cast<uint4*>(&tl[soff + 4 * 32 * LD]) = rw[0];
+    if (kDA < S) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) ra[0][p] = *reinterpret_cast<const uint4*>(src[p] + (size_t)kDA * KC);
+    }
+    if (kDW < S) rw[0] = *reinterpret_cast<const uint4*>(src[4] + (size_t)kDW * KC);
+    __syncthreads();
+    if (dbg) dbg[1] = wall_clock64();
+    // 24 = lcm(kDW, kDA): ring slots are compile-time indices inside the unrolled body
+    for (int s0 = 0; s0 < S; s0 += 24) {
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const int s = s0 + u;
+            if (s < S) {   // block-uniform
+                const int ua = (u + 1) % kDA, uw = (u + 1) % kDW;
+                // tile of step s+1 -> the LDS buffer last read in step s-1; then refill the ring slots
+                if (s + 1 < S) {
+                    uint16_t* dst = tl + ((s + 1) & 1) * (kRows * LD) + soff;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(dst + p * 32 * LD) = ra[ua][p];
+                    *reinterpret_cast<uint4*>(dst + 4 * 32 * LD) = rw[uw];
+                }
+                if (s + 1 + kDA < S) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) ra[ua][p] = *reinterpret_cast<const uint4*>(src[p] + (size_t)(s + 1 + kDA) * KC);
+                }
+                if (s + 1 + kDW < S) rw[uw] = *reinterpret_cast<const uint4*>(src[4] + (size_t)(s + 1 + kDW) * KC);
+                if (live) {
+                    const uint16_t* tb = tl + (s & 1) * (kRows * LD);
+                    const uint16_t* ab = tb + (wave * 16 + nl) * LD + g * 32;
+                    const uint16_t* wb = tb + (128 + nl) * LD + g * 32;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bf16x8 av = *reinterpret_cast<const bf16x8*>(ab + j * 8);
+                        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wb + j * 8);
+                        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wb + 16 * LD + j * 8);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc1, 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (dbg) dbg[2] = wall_clock64();
+    if (!live) return;
+    // accumulator layout: row = g*4 + r of the wave's 16 rows, column nl of the sub-tile
+    const int f0 = tile32_feature<EPI>(tile, nl, a.N), f1 = tile32_feature<EPI>(tile, 16 + nl, a.N);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int mi = m0 + wave * 16 + g * 4 + r;
+        if (mi >= a.M) continue;
+        float v0 = acc0[r], v1 = acc1[r];
+        if (EPI == EPI_STORE || EPI == EPI_RESID) {
+            if (gridDim.z > 1) {   // K split over blocks: fp32 partial slab of this K range
+                float* pr = a.part + ((size_t)kz * a.M + mi) * a.N;
+                if (f0 < a.N) pr[f0] = v0;
+                if (f1 < a.N) pr[f1] = v1;
+            } else {
+                const size_t o = (size_t)mi * a.ldy;
+                if (f0 < a.N) {
+                    if (a.bias != nullptr) v0 = __fadd_rn(v0, a.bias[f0]);
+                    a.y[o + f0] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o + f0], v0) : v0;
+                }
+                if (f1 < a.N) {
+                    if (a.bias != nullptr) v1 = __fadd_rn(v1, a.bias[f1]);
+                    a.y[o + f1] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o + f1], v1) : v1;
+                }
+            }
+        } else if (EPI == EPI_GELU) {   // gelu_tanh(c_fc(x) + b)  (R/t3.R:1303-1304)
+            uint16_t* yo = static_cast<uint16_t*>(a.yact) + (size_t)mi * a.N;
+            if (a.bias != nullptr) { v0 = __fadd_rn(v0, a.bias[f0]); v1 = __fadd_rn(v1, a.bias[f1]); }
+            const float i0 = 0.7978845608028654f * (v0 + 0.044715f * v0 * v0 * v0);
+            const float i1 = 0.7978845608028654f * (v1 + 0.044715f * v1 * v1 * v1);
+            if (f0 < a.N) yo[f0] = f2bf(0.5f * v0 * (1.0f + tanhf(i0)));
+            if (f1 < a.N) yo[f1] = f2bf(0.5f * v1 * (1.0f + tanhf(i1)));
+        } else if (EPI == EPI_SWIGLU) {   // silu(gate) * up  (R/llama.R:302, 307)
+            const float sg = 1.0f / (1.0f + expf(-v0));
+            static_cast<uint16_t*>(a.yact)[(size_t)mi * (a.N >> 1) + 16 * tile + nl] = f2bf(__fmul_rn(__fmul_rn(v0, sg), v1));
+        } else {  // EPI_ROPE_KV
+            const int pos = a.posmap[mi];
+            if (pos < 0) continue;
+            const int H = a.n_heads, hm = tile >> 1, i = ((tile & 1) << 4) + nl;
+            const int kind = hm / H, head = hm % H;
+            float lo = v0, hi = v1;
+            if (a.bias != nullptr) {
+                lo = __fadd_rn(lo, a.bias[hm * kHeadDim + i]);
+                hi = __fadd_rn(hi, a.bias[hm * kHeadDim + i + 32]);
+            }
+            if (kind < 2 && a.rope) {
+                const float cs = a.rope_cos[(size_t)pos * kHeadDim + i];
+                const float sn = a.rope_sin[(size_t)pos * kHeadDim + i];
+                const float nlo = __fadd_rn(__fmul_rn(lo, cs), __fmul_rn(-hi, sn));
+                const float nhi = __fadd_rn(__fmul_rn(hi, cs), __fmul_rn(lo, sn));
+                lo = nlo; hi = nhi;
+            }
+            if (kind == 0) {
+                float* q = a.q + (size_t)mi * (H * kHeadDim) + head * kHeadDim;
+                q[i] = lo; q[i + 32] = hi;
+            } else {
+                const int crow = a.rowmap ? a.rowmap[mi] : mi;
+                float* cb = (kind == 1 ? a.kcache : a.vcache) + (((size_t)crow * H + head) * a.max_len + pos) * kHeadDim;
+                cb[i] = lo; cb[i + 32] = hi;
+            }
+        }
+    }
+    if (dbg) dbg[3] = wall_clock64();
+}
+
+// y[m][i] = resid[m][i] + bias[i] + sum_s part[s][m][i], s ascending (the K-split of gemm_rows_bf16_kernel).
+// grid (M, N / 256): every thread fetches its <= 8 partials at once, then adds them in order.
+__global__ __launch_bounds__(256) void fold_partials_kernel(float* __restrict__ y, const float* __restrict__ resid,
+                                                            const float* __restrict__ part, int ks, const float* __restrict__ bias,
+                                                            int M, int N, int ldy) {
+    const int m = blockIdx.x, i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= N) return;
+    float p[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) p[s] = s < ks ? part[((size_t)s * M + m) * N + i] : 0.f;
+    const size_t o = (size_t)m * ldy + i;
+    const float r = resid != nullptr ? resid[o] : 0.f;
+    float v = p[0];
+#pragma unroll
+    for (int s = 1; s < 8; ++s)
+        if (s < ks) v += p[s];
+    if (bias != nullptr) v = __fadd_rn(v, bias[i]);
+    y[o] = resid != nullptr ? __fadd_rn(r, v) : v;
+}
+
+template <int EPI>
+hipError_t launch_gemm_rows_bf16(const GemmArgs& a, hipStream_t s) {
+    int tiles;
+    if (EPI == EPI_ROPE_KV) tiles = (a.N / kHeadDim) * 2;
+    else if (EPI == EPI_SWIGLU) tiles = a.N / 32;
+    else tiles = (a.N + 31) / 32;
+    const int chunks = (a.M + 127) / 128;
+    int ks = 1;
+    if ((EPI == EPI_RESID || EPI == EPI_STORE) && a.part != nullptr) {
+        // few feature tiles: split K over blocks until the launch has ~192 blocks (steps per block stay even)
+        while (ks < 8 && (long long)tiles * chunks * ks < 192 && a.K % (256 * ks * 2) == 0 &&
+               (size_t)(2 * ks) * a.M * a.N <= a.part_floats)
+            ks *= 2;
+    }
+    constexpr int lds = 2 * 160 * (128 + 8) * 2;   // 87,040 B: two step tiles
+    static bool attr_done = false;   // per EPI instantiation
+    if (!attr_done) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_bf16_kernel<EPI>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e0 != hipSuccess) return e0;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_rows_bf16_kernel<EPI>, dim3(tiles, chunks, ks), dim3(512), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ks == 1) return e;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(a.M, (a.N + 255) / 256), dim3(256), 0, s, a.y, EPI == EPI_RESID ? a.resid : nullptr, a.part, ks,
+                       a.bias, a.M, a.N, a.ldy);
+    return hipGetLastError();
+}
+
 template <typename G, int MT, int KS, int EPI>
 hipError_t launch_gemm_k(const GemmArgs& a, int tiles, hipStream_t s) {
     const int chunks = (a.M + MT * 16 - 1) / (MT * 16);
@@ -355,6 +591,16 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
         (a.N != 3 * a.n_heads * kHeadDim || !a.posmap || !a.q || !a.kcache || !a.vcache || a.max_len <= 0 ||
          (a.rope && (!a.rope_cos || !a.rope_sin))))
         return hipErrorInvalidValue;
+    static const bool gen1 = [] { const char* v = getenv("T3MI_GEMM_GEN1"); return v && v[0] == '1'; }();
+    if (wdtype == 1 && !gen1 && a.K % 256 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0)) {
+        switch (epilogue) {
+            case EPI_STORE: return launch_gemm_rows_bf16<EPI_STORE>(a, s);
+            case EPI_RESID: return launch_gemm_rows_bf16<EPI_RESID>(a, s);
+            case EPI_GELU: return launch_gemm_rows_bf16<EPI_GELU>(a, s);
+            case EPI_SWIGLU: return launch_gemm_rows_bf16<EPI_SWIGLU>(a, s);
+            case EPI_ROPE_KV: return launch_gemm_rows_bf16<EPI_ROPE_KV>(a, s);
+        }
+    }
     return wdtype == 1 ? launch_gemm_g<GemmBF16>(a, epilogue, s) : launch_gemm_g<GemmF32>(a, epilogue, s);
 }
 

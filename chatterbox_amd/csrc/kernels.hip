@@ -150,6 +150,16 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
 
     [[maybe_unused]] const int gwave = (int)blockIdx.x * nw + wave;
     T3K_STAMP(a, gwave, 0);
+    // Every argument the kernel reads, requested from the kernarg segment in ONE batch of scalar loads.  Left to
+    // itself the compiler loads each field next to its first use behind a wait of its own: six dependent kernarg round
+    // trips ahead of the first weight load (each a scalar-cache miss on a fresh launch) instead of one.
+    asm volatile("" ::"s"(a.W), "s"(a.x), "s"(a.ln_w), "s"(a.bias), "s"(a.y), "s"(a.resid), "s"(a.rowpos), "s"(a.rope_cur),
+                 "s"(a.kcache), "s"(a.vcache), "s"(a.pm), "s"(a.pl), "s"(a.pacc), "s"(a.eps), "s"(a.N), "s"(a.ldy),
+                 "s"(a.n_heads), "s"(a.max_len), "s"(a.n_split_max), "s"(a.keys_per_split), "s"(a.rope), "s"(n_chunks),
+                 "s"(a.pf[0].item.W), "s"(a.pf[1].item.W), "s"(a.progress));
+#ifdef T3K_STAMPS_KERNARG
+    T3K_STAMP(a, gwave, 5);   // experiment: kernel arguments landed
+#endif
     if (blockIdx.x == 0 && tid == 0) bump_progress(a.progress);
 
     // ---- 1. small L2-resident operands FIRST.  Vector-memory results return in issue order, so anything
@@ -219,9 +229,9 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
         for (int j = 0; j < NXJ; ++j) {
             const int i = (tid + j * nthr) * 4;
             if (i < K) {
-                gx[j] = *reinterpret_cast<const float4*>(a.ln_w + i);
 #pragma unroll
                 for (int r = 0; r < R; ++r) vx[r][j] = *reinterpret_cast<const float4*>(a.x + (size_t)r * K + i);
+                gx[j] = *reinterpret_cast<const float4*>(a.ln_w + i);
             }
         }
     } else {
@@ -249,8 +259,80 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
         }
     };
     if (c < n_chunks) load_chunk(c);
+    T3K_STAMP(a, gwave, 7);   // every load of the first chunk issued (nothing waited for yet)
+
+    // ---- 2b. L2 prefetch for later launches.  A batch-1 decode kernel streams only a few MB, so its fixed ramp
+    // (first-byte latency, tail) dominates; the weights of the NEXT launches do not depend on this launch's result,
+    // so every wave touches one dword per 128-byte line of its share of them, from a block on the XCD whose L2 the
+    // consuming blocks will read through (block b of every launch runs on XCD b % 8: round-robin placement; a wrong
+    // guess costs speed only).  Lines fetched this way survive the kernel boundary
+    // (scripts/micro/l2_prefetch_micro.hip: a 33.6 MB launch drops from 5.8 to 2.1 us).  Issued AFTER this launch's
+    // own loads: results return in issue order, so nothing of this launch waits behind them except the wave's exit.
+    constexpr int kPfMax = 3;
+    float pfv[2][kPfMax];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+        for (int u = 0; u < kPfMax; ++u) pfv[jb][u] = 0.f;
+        const PfJob& J = a.pf[jb];
+        if (J.item.W != nullptr) {
+            const PfItem& it = J.item;
+            const int slot = (int)blockIdx.x & 7;
+            const int nranks = ((int)gridDim.x - slot + 7) >> 3;                // blocks of this launch on this XCD
+            const int worker = ((int)blockIdx.x >> 3) * nw + wave, nworkers = nranks * nw;
+            const int lpr = (int)(it.row_bytes >> 7);                          // 128-byte lines per row
+            const int nb = (it.grid - slot + 7) >> 3;                          // consuming blocks on this XCD
+            const int lg_lpr = __builtin_ctz(lpr), lg_rows = __builtin_ctz(it.rows), lg_ngrp = __builtin_ctz(it.ngrp);
+            const int lg_lpu = lg_lpr + lg_rows + lg_ngrp;                     // lines of one block pass of the consumer
+            const int hp = it.rows >> 1, lg_hp = hp > 0 ? __builtin_ctz(hp) : 0;
+            const int passes = (it.n_chunks + it.grid * it.ngrp - 1) / (it.grid * it.ngrp);
+            const int total_lines = nb > 0 ? (passes * nb) << lg_lpu : 0;
+            const int n_wl = (total_lines + 63) >> 6;
+            const int wl_end = (int)(((long long)n_wl * J.end16) >> 4);
+            const char* Wb = static_cast<const char*>(it.W);
+#pragma unroll
+            for (int u = 0; u < kPfMax; ++u) {
+                const int wl = (int)(((long long)n_wl * J.begin16) >> 4) + worker + u * nworkers;
+                const int line = wl * 64 + lane;
+                if (wl < wl_end && line < total_lines) {
+                    const unsigned unit = (unsigned)line >> lg_lpu;
+                    const int l = line & ((1 << lg_lpu) - 1);
+                    const unsigned pass = unit / (unsigned)nb, bl = unit - pass * (unsigned)nb;
+                    const int blk = slot + 8 * (int)bl;
+                    const int cc = ((blk + (int)pass * it.grid) << lg_ngrp) + (l >> (lg_lpr + lg_rows));
+                    const int jj = (l >> lg_lpr) & (it.rows - 1);
+                    if (cc < it.n_chunks) {
+                        int row;
+                        if (it.kind == 1) {            // rotate_half pairs of one head (chunk_row<EPI_ROPE_KV>)
+                            const int lg_ph = 5 - lg_hp;
+                            row = ((cc >> lg_ph) << 6) + ((cc & ((1 << lg_ph) - 1)) << lg_hp) + (jj & (hp - 1)) + ((jj >> lg_hp) << 5);
+                        } else if (it.kind == 2) {     // gate rows and the matching up rows (chunk_row<EPI_SWIGLU>)
+                            row = (jj >> lg_hp) * (it.N >> 1) + (cc << lg_hp) + (jj & (hp - 1));
+                        } else {
+                            row = (cc << lg_rows) + jj;
+                        }
+                        if (row < it.N)
+                            pfv[jb][u] = *reinterpret_cast<const float*>(Wb + (size_t)row * it.row_bytes + ((size_t)(l & (lpr - 1)) << 7));
+                    }
+                }
+            }
+        }
+    }
 
     // ---- 3. prologue math while the weights are in flight
+#if defined(T3K_STAMPS) && !defined(T3K_STAMPS_KERNARG)
+    if (PRO == PRO_NORM) {
+        asm volatile("" ::"v"(vx[0][0].x));
+        T3K_STAMP(a, gwave, 5);   // this wave's x slices landed
+
+    } else if (PRO == PRO_PLAIN) {
+        asm volatile("" ::"v"(xv[0][0][0]));
+        T3K_STAMP(a, gwave, 5);
+    } else if (PRO == PRO_ATTN) {
+        asm volatile("" ::"v"(pmv[0][0]), "v"(pav[0][0].x));
+        T3K_STAMP(a, gwave, 5);
+    }
+#endif
     if (PRO == PRO_NORM) {
         static_assert(PRO != PRO_NORM || KSPLIT == 1, "norm prologue needs the whole row in one wave");
         // xs[r][k] = w_ln[k] * x[r][k]; the per-row scale rsqrt(mean(x^2)+eps) is a scalar and is applied
@@ -281,6 +363,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
             if (lane == 0) part[wave * R + r] = t;
         }
         __syncthreads();
+        T3K_STAMP(a, gwave, 6);   // past the block barrier of the norm prologue
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float t = 0.f;
@@ -566,7 +649,15 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
         }
     }
     T3K_STAMP(a, gwave, 4);   // stores issued
-
+    {
+        // keeps the prefetch loads alive; N is never negative (checked at launch), the compiler cannot know it
+        float t = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int u = 0; u < kPfMax; ++u) t += pfv[jb][u];
+        if (a.N < 0) a.y[0] = t;
+    }
 }
 
 // ---- single-query attention over the KV cache, split along the keys ---------------------------------
@@ -1210,6 +1301,14 @@ hipError_t launch_gemv_t(const GemvArgs& a, hipStream_t s) {
         g.ngrp = per_block;
         g.grid = grid;
         g.n_chunks = n_chunks;
+    }
+    if (a.geom_only) return hipSuccess;
+    for (int jb = 0; jb < 2; ++jb) {   // the in-kernel prefetch does its index math in shifts
+        const PfItem& it = a.pf[jb].item;
+        const int lpr = (int)(it.row_bytes >> 7);
+        if (it.W != nullptr && (lpr <= 0 || (lpr & (lpr - 1)) || it.rows <= 0 || (it.rows & (it.rows - 1)) || it.ngrp <= 0 ||
+                                (it.ngrp & (it.ngrp - 1)) || it.grid <= 0))
+            return hipErrorInvalidValue;
     }
     auto kfn = gemv_kernel<WT, R, NK, KSPLIT, ROWS, EPI, PRO>;
     if (lds > 64 * 1024) {

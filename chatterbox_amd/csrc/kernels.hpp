@@ -39,6 +39,13 @@ struct PfItem {
     int n_chunks = 0;
 };
 
+// In-kernel L2 prefetch job: this launch touches wave-loads [n * begin16 / 16, n * end16 / 16) of `item`, the weight
+// matrix of a LATER launch of the chain (n = 8 KB wave-loads of the item on one XCD).
+struct PfJob {
+    PfItem item;
+    int begin16 = 0, end16 = 0;
+};
+
 struct GemvArgs {
     const void* W = nullptr;      // [N, K] row-major (row = output feature), fp32 or bf16
     const float* x = nullptr;     // [rows, K]
@@ -67,6 +74,8 @@ struct GemvArgs {
     int rows_per_chunk = 0;       // output features per wave-chunk (0 = kernel default)
     int* progress = nullptr;      // device launch counter of the decode chain (block 0 adds 1), or nullptr
     PfItem* geom_out = nullptr;   // host: receives this launch's geometry for the prefetch plan
+    int geom_only = 0;            // host: 1 = report the geometry, launch nothing (plan dry run)
+    PfJob pf[2];                  // weights of later launches to pull into this XCD's L2 (item.W == nullptr: none)
 #ifdef T3K_STAMPS
     unsigned long long* stamps = nullptr;  // diagnostic build only: [T3K_STAMP_WAVES][T3K_STAMP_SLOTS] of this launch
 #endif
@@ -109,6 +118,9 @@ struct GemmArgs {
     float* kcache = nullptr;      // this layer: [cache rows][H][max_len][64]
     float* vcache = nullptr;
     int n_heads = 0, max_len = 0;
+    float* part = nullptr;        // scratch for K-split partial sums (EPI_STORE / EPI_RESID), or nullptr: no split
+    size_t part_floats = 0;
+    unsigned long long* dbg = nullptr;  // diagnostic (scripts/micro/gemm_micro.cpp): [block][4] clock stamps, or nullptr
 };
 
 struct EmbedArgs {                // token-by-token prefill input (R/t3.R:494, :505)

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -79,6 +80,7 @@ struct Session {
     int n_utt = 0, rpu = 1, rows = 0, max_len = 0, cap = 0, max_s0 = 0;
     int kps = 64, n_split = 1;  // attention split: keys per block, blocks per (row, head)
     bool gemm_mode = false;     // > 4 activation rows: linears run as MFMA GEMMs (batch_kernels.hip)
+    DevBuf gpart;               // GEMM-path K-split partial sums: [<= 8][rows][d] fp32
     DevBuf xn, attn_out, hact;  // GEMM-path activation rows (float with fp32 weights, bf16 with bf16 weights)
     t3mi_params prm{};
     std::vector<int32_t> s0;
@@ -86,6 +88,11 @@ struct Session {
         done, s0_dev, forced, dist_ids, dist_probs, dist_n, drawn;
     int n_forced = 0;
     // L2 weight prefetcher (see weight_prefetch_kernel): the step's weight-streaming launches in order
+    // in-kernel prefetch (GemvArgs::pf): each weight-streaming launch of the step pulls the weights of the next
+    // ones into L2; jobs[i] belongs to launch i of the step (same order as plan)
+    bool ikpf = false, jobs_ready = false, dry = false, in_step = false;
+    int li = 0;
+    std::vector<std::array<t3k::PfJob, 2>> jobs;
     bool pf_on = false, plan_ready = false, plan_collect = false;
     std::vector<t3k::PfItem> plan;
     DevBuf plan_dev, pf_dbg;   // pf_dbg: T3MI_PF_DEBUG=1 diagnostic (per item: counter lead and clock at start / end)
@@ -121,6 +128,9 @@ struct t3mi_model {
     hipStream_t pf_stream = nullptr;   // the prefetcher runs beside the decode chain
     DevBuf pf_state, pf_sink;
     bool pf_ok = false;                // placement census passed and T3MI_PREFETCH != 0
+    bool ikpf_ok = false;              // in-kernel L2 prefetch: experiment, T3MI_IKPF=1 turns it on (the consumer
+                                       // gains 1.5-1.8 us, the prefetching launch pays 2.6-3.3 us: HBM time only moves)
+    int ikpf_split16 = 8, ikpf_big_mb = 24;   // big items are shared with the launch before: its share in 1/16, threshold
     int pf_lookahead = 2, pf_blocks = 64, pf_depth = 2, pf_max_polls = 4000;
     int tune[5] = {8, 4, 8, 8, 8};  // waves per block: qkv, o_proj, gate_up, down, head (T3MI_WAVES=a,b,c,d,e)
     int tune_rows[5] = {2, 1, 2, 2, 2};  // output rows per wave-chunk, same order (T3MI_ROWS=a,b,c,d,e)
@@ -456,7 +466,16 @@ inline int* pf_progress(t3mi_model* m, Session* s) {
     return m->pf_state.as<int>() + t3k::kPfProgress;
 }
 inline void pf_note(Session* s, const t3k::PfItem& it) {
-    if (s->pf_on && s->plan_collect) s->plan.push_back(it);
+    if ((s->pf_on || s->ikpf) && s->plan_collect) s->plan.push_back(it);
+}
+// launch index within the decode step (-1 outside a step) and that launch's prefetch jobs
+inline int step_launch_index(Session* s) { return s->in_step ? s->li++ : -1; }
+inline void pf_jobs(Session* s, int li, t3k::GemvArgs& a) {
+    a.geom_only = s->dry ? 1 : 0;
+    if (s->jobs_ready && li >= 0 && li < (int)s->jobs.size()) {
+        a.pf[0] = s->jobs[li][0];
+        a.pf[1] = s->jobs[li][1];
+    }
 }
 
 struct StepTimer {  // optional per-launch events for t3mi_session_profile_step
@@ -502,6 +521,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             t3k::PfItem geom;
             a.progress = pf_progress(m, s); a.geom_out = &geom;
             T3MI_SET_STAMPS(a);
+            pf_jobs(s, step_launch_index(s), a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_ROPE_KV, m->wdtype, m->stream));
             pf_note(s, geom);
             r0 += rg;
@@ -515,8 +535,9 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.rows = s->rows; a.n_heads = H; a.max_len = s->max_len;
             a.n_split_max = s->n_split; a.keys_per_split = s->kps;
             a.progress = pf_progress(m, s);
+            (void)step_launch_index(s);
             T3MI_SET_STAMPS(a);
-            HIPCHK(t3k::launch_attn_decode(a, m->stream));
+            if (!s->dry) HIPCHK(t3k::launch_attn_decode(a, m->stream));
             pf_note(s, t3k::PfItem{});
         }
         if (tm) tm->mark(K_ATTN);
@@ -536,6 +557,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             t3k::PfItem geom;
             a.progress = pf_progress(m, s); a.geom_out = &geom;
             T3MI_SET_STAMPS(a);
+            pf_jobs(s, step_launch_index(s), a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
             pf_note(s, geom);
             r0 += rg;
@@ -553,6 +575,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             t3k::PfItem geom;
             a.progress = pf_progress(m, s); a.geom_out = &geom;
             T3MI_SET_STAMPS(a);
+            pf_jobs(s, step_launch_index(s), a);
             HIPCHK(t3k::launch_gemv(a, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, m->wdtype, m->stream));
             pf_note(s, geom);
             r0 += rg;
@@ -569,6 +592,7 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             t3k::PfItem geom;
             a.progress = pf_progress(m, s); a.geom_out = &geom;
             T3MI_SET_STAMPS(a);
+            pf_jobs(s, step_launch_index(s), a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
             pf_note(s, geom);
             r0 += rg;
@@ -629,6 +653,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, const GemmCtx& c, StepTimer* tm) 
             t3k::GemmArgs a;
             a.W = lw.wo; a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
             a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_o;
+            a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
             HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, m->wdtype, st));
         }
         if (tm) tm->mark(K_OPROJ);
@@ -645,6 +670,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, const GemmCtx& c, StepTimer* tm) 
             t3k::GemmArgs a;
             a.W = lw.wdown; a.A = c.hact; a.M = c.M; a.N = d; a.K = F;
             a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_down;
+            a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
             HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, m->wdtype, st));
         }
         if (tm) tm->mark(K_DOWN);
@@ -689,7 +715,8 @@ int run_head(t3mi_model* m, Session* s, StepTimer* tm) {
         t3k::PfItem geom;
         a.progress = pf_progress(m, s); a.geom_out = &geom;
         T3MI_SET_STAMPS(a);
-        HIPCHK(t3k::launch_gemv(a, t3k::EPI_STORE, m->wdtype, m->stream));
+        pf_jobs(s, step_launch_index(s), a);
+            HIPCHK(t3k::launch_gemv(a, t3k::EPI_STORE, m->wdtype, m->stream));
         pf_note(s, geom);
         r0 += rg;
     }
@@ -717,7 +744,8 @@ int run_sampler(t3mi_model* m, Session* s, StepTimer* tm) {
     a.drawn = s->drawn.as<int>();
     a.dist_cap = m->V;
     a.progress = pf_progress(m, s);
-    HIPCHK(t3k::launch_sampler(a, m->stream));
+    (void)step_launch_index(s);
+    if (!s->dry) HIPCHK(t3k::launch_sampler(a, m->stream));
     pf_note(s, t3k::PfItem{});
     if (tm) tm->mark(K_SAMPLER);
     return T3MI_OK;
@@ -725,11 +753,61 @@ int run_sampler(t3mi_model* m, Session* s, StepTimer* tm) {
 
 int run_decode_step(t3mi_model* m, Session* s, StepTimer* tm) {
     int rc;
-    if ((rc = run_sampler(m, s, tm))) return rc;
-    if (s->gemm_mode) rc = run_layers_gemm(m, s, decode_ctx(s), tm);
-    else rc = run_layers(m, s, tm);
+    s->li = 0;
+    s->in_step = true;
+    if (!(rc = run_sampler(m, s, tm))) {
+        if (s->gemm_mode) rc = run_layers_gemm(m, s, decode_ctx(s), tm);
+        else rc = run_layers(m, s, tm);
+    }
+    if (!rc) rc = run_head(m, s, tm);
+    s->in_step = false;
+    return rc;
+}
+
+// Prefetch plan of the in-kernel L2 prefetch: a dry pass over one decode step records every launch's geometry, then
+// every weight matrix is assigned to the weight-streaming launch before it (wrapping: the head prefetches layer 0's
+// QKV weights of the next step).  Matrices above ikpf_big_mb are shared with the streaming launch before that one.
+int plan_ikpf(t3mi_model* m, Session* s) {
+    if (!s->ikpf || s->jobs_ready) return T3MI_OK;
+    const long long bumps0 = s->bumps;
+    s->plan.clear();
+    s->plan_collect = true;
+    s->dry = true;
+    int rc = run_decode_step(m, s, nullptr);
+    s->dry = false;
+    s->plan_collect = false;
+    s->bumps = bumps0;
     if (rc) return rc;
-    return run_head(m, s, tm);
+    const int n = (int)s->plan.size();
+    s->jobs.assign(n, {});
+    std::vector<int> streaming;
+    for (int i = 0; i < n; ++i)
+        if (s->plan[i].W != nullptr) streaming.push_back(i);
+    const int ns = (int)streaming.size();
+    auto add_job = [&](int launch, const t3k::PfItem& it, int b16, int e16) {
+        for (auto& j : s->jobs[launch])
+            if (j.item.W == nullptr) {
+                j.item = it;
+                j.begin16 = b16;
+                j.end16 = e16;
+                return;
+            }
+    };
+    for (int k = 0; k < ns && ns >= 3; ++k) {
+        const t3k::PfItem& it = s->plan[streaming[k]];
+        const int p1 = streaming[(k + ns - 1) % ns], p2 = streaming[(k + ns - 2) % ns];
+        const double mb = (double)it.N * it.row_bytes / 1e6;
+        if (const char* v = std::getenv("T3MI_IKPF_MIN_MB")) if (mb < std::atof(v)) continue;   // experiments
+        if (const char* v = std::getenv("T3MI_IKPF_MAX_MB")) if (mb > std::atof(v)) continue;
+        if (mb > m->ikpf_big_mb && m->ikpf_split16 > 0) {
+            add_job(p2, it, 0, m->ikpf_split16);
+            add_job(p1, it, m->ikpf_split16, 16);
+        } else {
+            add_job(p1, it, 0, 16);
+        }
+    }
+    s->jobs_ready = true;
+    return T3MI_OK;
 }
 
 int upload_plan(t3mi_model* m, Session* s) {
@@ -872,6 +950,10 @@ int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model*
         m->pf_ok = ok && pe && pe[0] == '1';   // experiment, off by default: measured slower
         HIPCHK(hipMemcpy(m->pf_state.p, st, stv.size() * 4, hipMemcpyHostToDevice));
         if (const char* v = std::getenv("T3MI_PF_LOOKAHEAD")) m->pf_lookahead = std::max(1, std::atoi(v));
+        if (const char* v = std::getenv("T3MI_IKPF")) m->ikpf_ok = v[0] == '1';
+        m->ikpf_ok = m->ikpf_ok && ok;   // needs the same block -> XCD placement in every launch
+        if (const char* v = std::getenv("T3MI_IKPF_SPLIT")) m->ikpf_split16 = std::min(16, std::max(0, std::atoi(v)));
+        if (const char* v = std::getenv("T3MI_IKPF_BIG_MB")) m->ikpf_big_mb = std::max(1, std::atoi(v));
         if (const char* v = std::getenv("T3MI_PF_MODE")) m->pf_max_polls |= (std::atoi(v) & 3) << 24;
         if (const char* v = std::getenv("T3MI_PF_DEPTH")) {
             const int dp = std::atoi(v);
@@ -1026,8 +1108,10 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         HIPCHK(s->xn.alloc(rows * d * as));
         HIPCHK(s->attn_out.alloc(rows * d * as));
         HIPCHK(s->hact.alloc(rows * F * as));
+        HIPCHK(s->gpart.alloc(s->gemm_mode ? 8 * rows * d * 4 : 16));
     }
     s->pf_on = m->pf_ok && !s->gemm_mode && rows <= 4;
+    s->ikpf = m->ikpf_ok && !s->pf_on && !s->gemm_mode && rows <= 4;
     if (s->pf_on) HIPCHK(hipMemsetAsync(m->pf_state.as<int>() + t3k::kPfProgress, 0, 4, m->stream));
     HIPCHK(s->logits.alloc(rows * V * 4));
     HIPCHK(s->rowpos.alloc(rows * 4));
@@ -1191,6 +1275,7 @@ int t3mi_session_decode(t3mi_model* m, int n_steps) {
     if (n_steps <= 0) return fail(T3MI_ERR_ARG, "n_steps must be positive");
     Session* s = m->sess.get();
     HIPCHK(hipSetDevice(m->device));
+    if ((rc = plan_ikpf(m, s))) return rc;
     if (m->use_graph && !s->graph_tried) {
         if ((rc = build_graph(m, s))) return rc;
     }
@@ -1321,6 +1406,7 @@ int t3mi_session_profile_step(t3mi_model* m, t3mi_kstat* stats, int cap, int* n_
     StepTimer tm;
     tm.s = m->stream;
     tm.on = true;
+    if ((rc = plan_ikpf(m, s))) return rc;
     tm.mark(-1);
     if (!s->plan_collect) (void)launch_prefetch(m, s);
     rc = run_decode_step(m, s, &tm);

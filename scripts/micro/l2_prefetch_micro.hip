@@ -26,6 +26,17 @@ __global__ void k_flush(const float4* __restrict__ buf, size_t n4, float* sink) 
 __global__ __launch_bounds__(kThreads) void k_prev(float* __restrict__ x, int xn, const float* __restrict__ W, size_t slice_floats,
                                                    int shift, int do_pf, float* sink, float xval) {
     const int b = blockIdx.x;
+    if (xn < 0) {
+        // the decode chain's pattern: 2 rows x 1024 features, block b owns 4 consecutive features of each row, so every
+        // 128-byte line of x is written in 16-byte pieces by 8 blocks on 8 different XCDs
+        xn = -xn;
+        if (threadIdx.x < 8) x[(threadIdx.x >> 2) * 1024 + 4 * b + (threadIdx.x & 3)] = xval + (float)b;
+    } else if (xn >= (1 << 20)) {
+        // same pieces, but the 8 blocks that share a line sit on ONE XCD (blocks with equal b % 8)
+        xn -= (1 << 20);
+        const int line = (b & 7) + 8 * (b >> 6), piece = (b >> 3) & 7;
+        if (threadIdx.x < 8) x[(threadIdx.x >> 2) * 1024 + 32 * line + 4 * piece + (threadIdx.x & 3)] = xval + (float)b;
+    } else
     for (int i = b * kThreads + threadIdx.x; i < xn; i += kWG * kThreads) x[i] = xval + (float)i;
     if (do_pf) {
         const int tb = (b + shift) % kWG;
@@ -111,19 +122,37 @@ int main() {
         const size_t slice_floats = (size_t)nv * kThreads * 4;
         const double mb = (double)slice_floats * 4 * kWG / 1e6;
         const char* names[] = {"cold (flush, HBM)", "repeat (same launch again)", "prefetch by same-XCD block", "prefetch by block+1 (other XCD)",
-                               "prefetch + repeat every launch"};
-        for (int sc = 0; sc < 5; ++sc) {
+                               "prefetch + repeat every launch", "prefetch same-XCD, replayed hipGraph", "cold, replayed hipGraph",
+                               "cold, x written in 16-B pieces from 8 XCDs", "cold, x pieces of a line from one XCD"};
+        for (int sc = 0; sc < 9; ++sc) {
             std::vector<Res> rs;
+            hipGraphExec_t ge = nullptr;
+            if (sc == 5 || sc == 6) {   // the same three launches as scenario 2 / 0, captured once and replayed
+                hipGraph_t g;
+                CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                hipLaunchKernelGGL(k_flush, dim3(2048), dim3(256), 0, st, (const float4*)flushbuf, FB / 16, sink);
+                hipLaunchKernelGGL(k_prev, dim3(kWG), dim3(kThreads), 0, st, x, 4096, W, slice_floats, 0, sc == 5 ? 1 : 0, sink, 0.5f);
+                hipLaunchKernelGGL(kread, dim3(kWG), dim3(kThreads), 0, st, (const float*)x, (const float*)W, slice_floats, y, stamps);
+                CK(hipStreamEndCapture(st, &g));
+                CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            }
             for (int rep = 0; rep < 9; ++rep) {
                 Res r{};
-                if (sc != 1 && sc != 4) hipLaunchKernelGGL(k_flush, dim3(2048), dim3(256), 0, st, (const float4*)flushbuf, FB / 16, sink);
+                if (sc == 5 || sc == 6) {
+                    CK(hipGraphLaunch(ge, st));
+                    if (collect(r)) return 1;
+                    rs.push_back(r);
+                    continue;
+                }
+                if (sc != 1 && sc != 4 && sc != 5 && sc != 6) hipLaunchKernelGGL(k_flush, dim3(2048), dim3(256), 0, st, (const float4*)flushbuf, FB / 16, sink);
                 if (sc == 1) {
                     hipLaunchKernelGGL(k_prev, dim3(kWG), dim3(kThreads), 0, st, x, 4096, W, slice_floats, 0, 0, sink, (float)rep);
                     hipLaunchKernelGGL(kread, dim3(kWG), dim3(kThreads), 0, st, (const float*)x, (const float*)W, slice_floats, y, stamps);
                 }
-                const int pf = (sc >= 2) ? 1 : 0;
+                const int pf = (sc >= 2 && sc < 7) ? 1 : 0;
                 const int shift = (sc == 3) ? 1 : 0;
-                hipLaunchKernelGGL(k_prev, dim3(kWG), dim3(kThreads), 0, st, x, 4096, W, slice_floats, shift, pf, sink, (float)rep + 0.5f);
+                const int xmode = sc == 7 ? -4096 : (sc == 8 ? (1 << 20) + 4096 : 4096);
+                hipLaunchKernelGGL(k_prev, dim3(kWG), dim3(kThreads), 0, st, x, xmode, W, slice_floats, shift, pf, sink, (float)rep + 0.5f);
                 hipLaunchKernelGGL(kread, dim3(kWG), dim3(kThreads), 0, st, (const float*)x, (const float*)W, slice_floats, y, stamps);
                 if (collect(r)) return 1;
                 rs.push_back(r);

@@ -49,13 +49,18 @@ for i in range(n):
         t0 = first
     rec = dict(waves=int(live.sum()), skew=(s0.max() - first) / 100.0, dur=(end - first) / 100.0,
                gap=(first - prev_end) / 100.0 if prev_end is not None else 0.0)
-    for j, nm in [(1, "x_ready"), (2, "w_fma"), (3, "reduced"), (4, "stored")]:
+    for j, nm in [(7, "issued"), (5, "x_landed"), (6, "barrier"), (1, "x_ready"), (2, "w_fma"), (3, "reduced"), (4, "stored")]:
         v = st[live, j]
         ok = v > 0
         if ok.any():
             rel = (v[ok] - first) / 100.0
             rec[nm + "_med"] = float(np.median(rel))
             rec[nm + "_max"] = float(rel.max())
+    ok7 = st[live, 7] > 0
+    if ok7.any():   # per wave: own start -> all loads issued
+        d = (st[live, 7][ok7] - st[live, 0][ok7]) / 100.0
+        rec["own_issue_med"] = float(np.median(d))
+        rec["own_issue_max"] = float(d.max())
     rows.setdefault(kind, []).append(rec)
     prev_end = end
 print(f"dtype={dtype}  launches={n}  step span={(prev_end - t0) / 100.0:.1f} us")
