@@ -210,7 +210,7 @@ __global__ __launch_bounds__(KS * 64) void mfma_gemm_kernel(GemmArgs a) {
                 q[i] = lo; q[i + 32] = hi;
             } else {
                 const int crow = a.rowmap ? a.rowmap[mi] : mi;
-                float* cb = (kind == 1 ? a.kcache : a.vcache) + (((size_t)crow * H + head) * a.max_len + pos) * kHeadDim;
+                float* cb = static_cast<float*>(kind == 1 ? a.kcache : a.vcache) + (((size_t)crow * H + head) * a.max_len + pos) * kHeadDim;
                 cb[i] = lo; cb[i + 32] = hi;
             }
         }
@@ -289,6 +289,114 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
             o /= den;
         }
         Act<AT>::store(out + (size_t)qi * d + i, o);
+    }
+}
+
+
+// ---- many-row attention: one block per (query item, head) ----------------------------------------------------
+// (R/llama.R:257-264, src/t3_decode.cpp:151-160.)  With >= 8 rows x 16 heads there are enough (item, head) pairs
+// to fill the chip without splitting the keys over blocks, so the softmax finishes inside the block and the output
+// rows are written normalised, in the o_proj GEMM's activation type: no partial buffers, no merge launch.
+// A wave reads 8 keys per instruction: lane = (key kg = lane >> 3, dims dc*8 .. dc*8+7), i.e. 1 KiB (bf16) or
+// 2 KiB (fp32) of contiguous cache per load; the 4 waves interleave key groups.  Every (wave, kg) stream keeps its
+// own running max / sum / accumulator (no cross-lane traffic inside the loop) and the 32 streams merge once through
+// LDS in a fixed order.
+template <typename KVT> struct KvLoad;
+template <> struct KvLoad<float> {
+    __device__ static __forceinline__ void load8(const float* p, float (&o)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+};
+template <> struct KvLoad<uint16_t> {
+    __device__ static __forceinline__ void load8(const uint16_t* p, float (&o)[8]) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xFFFF0000u);
+        o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xFFFF0000u);
+        o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xFFFF0000u);
+        o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xFFFF0000u);
+    }
+};
+
+template <typename KVT, typename OT>
+__global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsArgs a) {
+    __shared__ float sm_m[32], sm_l[32];
+    __shared__ __attribute__((aligned(16))) float sm_acc[32][kHeadDim + 4];
+    const int h = blockIdx.x, qi = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = lane >> 3, dc = lane & 7;
+    const int pos = a.posmap[qi];
+    const int d = a.n_heads * kHeadDim;
+    OT* orow = static_cast<OT*>(a.out) + (size_t)qi * d + h * kHeadDim;
+    if (pos < 0) {   // inactive item: defined (zero) activation row, as the merge kernel wrote
+        if (tid < kHeadDim) Act<OT>::store(orow + tid, 0.f);
+        return;
+    }
+    const int L = pos + 1;
+    const int crow = a.rowmap ? a.rowmap[qi] : qi;
+    const size_t base = ((size_t)crow * a.n_heads + h) * a.max_len * kHeadDim;
+    const KVT* kp = static_cast<const KVT*>(a.kcache) + base + dc * 8;
+    const KVT* vp = static_cast<const KVT*>(a.vcache) + base + dc * 8;
+    float qv[8];
+    {
+        const float* qp = a.q + (size_t)qi * d + h * kHeadDim + dc * 8;
+        const float4 q0 = *reinterpret_cast<const float4*>(qp), q1 = *reinterpret_cast<const float4*>(qp + 4);
+        // scores are q.k / sqrt(64): the scale is applied to the dot product (R/llama.R:259)
+        qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+    }
+    float m_run = -INFINITY, l_run = 0.f, acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    // keys of this stream: wave*8 + kg, then every 32nd
+    for (int k0 = wave * 8 + kg; k0 < L + 31; k0 += 64) {
+        // two keys per trip (k0 and k0 + 32) so that four cache loads are in flight per lane
+        const int ka = k0, kb = k0 + 32;
+        const bool oka = ka < L, okb = kb < L;
+        float kva[8], kvb[8], vva[8], vvb[8];
+        KvLoad<KVT>::load8(kp + (size_t)(oka ? ka : 0) * kHeadDim, kva);
+        KvLoad<KVT>::load8(kp + (size_t)(okb ? kb : 0) * kHeadDim, kvb);
+        KvLoad<KVT>::load8(vp + (size_t)(oka ? ka : 0) * kHeadDim, vva);
+        KvLoad<KVT>::load8(vp + (size_t)(okb ? kb : 0) * kHeadDim, vvb);
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sa = fmaf(qv[e], kva[e], sa);
+            sb = fmaf(qv[e], kvb[e], sb);
+        }
+        // sum over the 8 lanes of the key (lanes kg*8 .. kg*8+7)
+        sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
+        sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
+        sa += __shfl_xor(sa, 4, 64); sb += __shfl_xor(sb, 4, 64);
+        sa = oka ? sa * 0.125f : -INFINITY;
+        sb = okb ? sb * 0.125f : -INFINITY;
+        const float mn = fmaxf(m_run, fmaxf(sa, sb));
+        if (mn > -INFINITY) {
+            const float sc = expf(m_run - mn), pa = expf(sa - mn), pb = expf(sb - mn);
+            l_run = fmaf(l_run, sc, pa + pb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pb, vvb[e], fmaf(pa, vva[e], acc[e] * sc));
+            m_run = mn;
+        }
+    }
+    // merge the 32 streams (4 waves x 8 key groups): stream id = wave*8 + kg
+    const int sid = wave * 8 + kg;
+    if (dc == 0) { sm_m[sid] = m_run; sm_l[sid] = l_run; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm_acc[sid][dc * 8 + e] = acc[e];
+    __syncthreads();
+    if (tid < kHeadDim) {
+        float M = -INFINITY;
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) M = fmaxf(M, sm_m[s2]);
+        float den = 0.f, o = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) {
+            const float ms = sm_m[s2];
+            const float ws = ms > -INFINITY ? expf(ms - M) : 0.f;
+            den = fmaf(ws, sm_l[s2], den);
+            o = fmaf(ws, sm_acc[s2][tid], o);
+        }
+        Act<OT>::store(orow + tid, o / den);
     }
 }
 
@@ -476,8 +584,14 @@ __global__ __launch_bounds__(512) void gemm_rows_bf16_kernel(GemmArgs a) {
                 q[i] = lo; q[i + 32] = hi;
             } else {
                 const int crow = a.rowmap ? a.rowmap[mi] : mi;
-                float* cb = (kind == 1 ? a.kcache : a.vcache) + (((size_t)crow * H + head) * a.max_len + pos) * kHeadDim;
-                cb[i] = lo; cb[i + 32] = hi;
+                const size_t co = (((size_t)crow * H + head) * a.max_len + pos) * kHeadDim;
+                if (a.kv_bf16) {
+                    uint16_t* cb = static_cast<uint16_t*>(kind == 1 ? a.kcache : a.vcache) + co;
+                    cb[i] = f2bf(lo); cb[i + 32] = f2bf(hi);
+                } else {
+                    float* cb = static_cast<float*>(kind == 1 ? a.kcache : a.vcache) + co;
+                    cb[i] = lo; cb[i + 32] = hi;
+                }
             }
         }
     }
@@ -633,6 +747,17 @@ hipError_t launch_attn_merge(const float* pm, const float* pl, const float* pacc
     else
         hipLaunchKernelGGL(attn_merge_kernel<float>, dim3(M), dim3(256), 0, s, pm, pl, pacc, posmap,
                            static_cast<float*>(out), H, n_split_max, kps);
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
+    if (!a.q || !a.kcache || !a.vcache || !a.posmap || !a.out || a.M <= 0 || a.n_heads <= 0 || a.max_len <= 0)
+        return hipErrorInvalidValue;
+    const dim3 grid(a.n_heads, a.M), block(256);
+    if (a.kv_bf16 && a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, uint16_t>), grid, block, 0, s, a);
+    else if (a.kv_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, float>), grid, block, 0, s, a);
+    else if (a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<float, uint16_t>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_rows_kernel<float, float>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 

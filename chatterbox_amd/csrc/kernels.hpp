@@ -115,8 +115,9 @@ struct GemmArgs {
     const float* rope_cos = nullptr;  // [max_len, 64]
     const float* rope_sin = nullptr;
     float* q = nullptr;           // [M, H*64] fp32
-    float* kcache = nullptr;      // this layer: [cache rows][H][max_len][64]
-    float* vcache = nullptr;
+    void* kcache = nullptr;       // this layer: [cache rows][H][max_len][64], fp32 or bf16 (kv_bf16)
+    void* vcache = nullptr;
+    int kv_bf16 = 0;
     int n_heads = 0, max_len = 0;
     float* part = nullptr;        // scratch for K-split partial sums (EPI_STORE / EPI_RESID), or nullptr: no split
     size_t part_floats = 0;
@@ -181,6 +182,18 @@ hipError_t launch_rmsnorm_rows(const float* x, const float* w, float eps, void* 
                                hipStream_t s);
 hipError_t launch_attn_merge(const float* pm, const float* pl, const float* pacc, const int* posmap, void* out, int M,
                              int H, int n_split_max, int kps, int act_bf16, hipStream_t s);
+// many-row attention (batched decode, prefill): one block per (query item, head) over keys 0..posmap[item]; writes
+// the normalised output rows in the activation type of the o_proj GEMM.  kv_bf16 / out_bf16: element types.
+struct AttnRowsArgs {
+    const float* q = nullptr;       // [M, H*64] fp32 (RoPE applied)
+    const void* kcache = nullptr;   // this layer: [cache rows][H][max_len][64]
+    const void* vcache = nullptr;
+    const int* posmap = nullptr;    // [M] last key of item m (< 0 = inactive)
+    const int* rowmap = nullptr;    // [M] cache row of item m (nullptr = identity)
+    void* out = nullptr;            // [M, H*64]
+    int M = 0, n_heads = 0, max_len = 0, kv_bf16 = 0, out_bf16 = 0;
+};
+hipError_t launch_attn_rows(const AttnRowsArgs& a, hipStream_t s);
 hipError_t launch_gather_rows(const float* const* src_rows, float* x, int M, int d, hipStream_t s);
 // ---- L2 weight prefetcher (runs beside the decode chain on its own stream; performance hint only) ----
 // state: int[32] device words: [0] progress counter, [8..15] per-XCD tickets, [16..23] slot_of_xcc

@@ -80,6 +80,7 @@ struct Session {
     int n_utt = 0, rpu = 1, rows = 0, max_len = 0, cap = 0, max_s0 = 0;
     int kps = 64, n_split = 1;  // attention split: keys per block, blocks per (row, head)
     bool gemm_mode = false;     // > 4 activation rows: linears run as MFMA GEMMs (batch_kernels.hip)
+    bool kv_bf16 = false;       // KV slabs hold bf16 (many-row regime with bf16 weights), else fp32
     DevBuf gpart;               // GEMM-path K-split partial sums: [<= 8][rows][d] fp32
     DevBuf xn, attn_out, hact;  // GEMM-path activation rows (float with fp32 weights, bf16 with bf16 weights)
     t3mi_params prm{};
@@ -621,12 +622,12 @@ int run_layers_gemm(t3mi_model* m, Session* s, const GemmCtx& c, StepTimer* tm) 
     const int d = m->d, F = m->F, H = m->H;
     const int abf = m->wdtype == T3MI_W_BF16 ? 1 : 0;
     const bool turbo = m->variant == T3MI_VARIANT_TURBO;
-    const size_t layer_kv = (size_t)s->rows * H * s->max_len * 64;
+    const size_t layer_kv = (size_t)s->rows * H * s->max_len * 64 * (s->kv_bf16 ? 2 : 4);   // bytes
     hipStream_t st = m->stream;
     for (int l = 0; l < m->n_layers; ++l) {
         const LayerW& lw = m->layers[l];
-        float* kc = s->kc.as<float>() + layer_kv * l;
-        float* vc = s->vc.as<float>() + layer_kv * l;
+        char* kc = s->kc.as<char>() + layer_kv * l;
+        char* vc = s->vc.as<char>() + layer_kv * l;
         if (turbo) HIPCHK(t3k::launch_layernorm_rows(c.x, lw.ln1, lw.ln1_b, m->eps, c.xn, c.M, d, abf, st));
         else HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln1, m->eps, c.xn, c.M, d, abf, st));
         {
@@ -634,21 +635,19 @@ int run_layers_gemm(t3mi_model* m, Session* s, const GemmCtx& c, StepTimer* tm) 
             a.W = lw.wqkv; a.A = c.xn; a.M = c.M; a.N = 3 * d; a.K = d;
             a.posmap = c.posmap; a.rowmap = c.rowmap;
             a.rope_cos = m->rope_cos.as<float>(); a.rope_sin = m->rope_sin.as<float>();
-            a.q = c.q; a.kcache = kc; a.vcache = vc; a.n_heads = H; a.max_len = s->max_len;
+            a.q = c.q; a.kcache = kc; a.vcache = vc; a.kv_bf16 = s->kv_bf16 ? 1 : 0; a.n_heads = H; a.max_len = s->max_len;
             if (turbo) { a.bias = lw.b_qkv; a.rope = 0; }
             HIPCHK(t3k::launch_gemm(a, t3k::EPI_ROPE_KV, m->wdtype, st));
         }
         if (tm) tm->mark(K_QKV);
         {
-            t3k::AttnArgs a;
-            a.q = c.q; a.kcache = kc; a.vcache = vc; a.rowpos = c.posmap; a.rowmap = c.rowmap;
-            a.pm = c.pm; a.pl = c.pl; a.pacc = c.pacc;
-            a.rows = c.M; a.n_heads = H; a.max_len = s->max_len;
-            a.n_split_max = c.n_split; a.keys_per_split = c.kps;
-            HIPCHK(t3k::launch_attn_decode(a, st));
+            t3k::AttnRowsArgs a;
+            a.q = c.q; a.kcache = kc; a.vcache = vc; a.posmap = c.posmap; a.rowmap = c.rowmap;
+            a.out = c.attn_out; a.M = c.M; a.n_heads = H; a.max_len = s->max_len;
+            a.kv_bf16 = s->kv_bf16 ? 1 : 0; a.out_bf16 = abf;
+            HIPCHK(t3k::launch_attn_rows(a, st));
         }
         if (tm) tm->mark(K_ATTN);
-        HIPCHK(t3k::launch_attn_merge(c.pm, c.pl, c.pacc, c.posmap, c.attn_out, c.M, H, c.n_split, c.kps, abf, st));
         {
             t3k::GemmArgs a;
             a.W = lw.wo; a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
@@ -1088,7 +1087,15 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     if (rc) return rc;
 
     const size_t d = m->d, F = m->F, V = m->V, rows = s->rows, U = n_utt;
-    const size_t kv = (size_t)m->n_layers * rows * m->H * s->max_len * 64 * 4;
+    {
+        const char* gm = std::getenv("T3MI_GEMM_ROWS");  // rows above which the MFMA path is used (default 4)
+        const int thr = gm ? std::atoi(gm) : 4;
+        s->gemm_mode = (int)rows > thr;
+        const char* kve = std::getenv("T3MI_KV");        // "f32" keeps fp32 KV slabs in the many-row bf16 regime
+        const char* g1 = std::getenv("T3MI_GEMM_GEN1");
+        s->kv_bf16 = s->gemm_mode && m->wdtype == T3MI_W_BF16 && d % 256 == 0 && !(kve && kve[0] == 'f') && !(g1 && g1[0] == '1');
+    }
+    const size_t kv = (size_t)m->n_layers * rows * m->H * s->max_len * 64 * (s->kv_bf16 ? 2 : 4);
     HIPCHK(s->kc.alloc(kv));
     HIPCHK(s->vc.alloc(kv));
     HIPCHK(s->x.alloc(rows * d * 4));
@@ -1101,9 +1108,6 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     HIPCHK(s->pacc.alloc(rows * m->H * (size_t)s->n_split * 64 * 4));
     HIPCHK(s->hbuf.alloc(rows * F * 4));
     {
-        const char* gm = std::getenv("T3MI_GEMM_ROWS");  // rows above which the MFMA path is used (default 4)
-        const int thr = gm ? std::atoi(gm) : 4;
-        s->gemm_mode = (int)rows > thr;
         const size_t as = m->wdtype == T3MI_W_BF16 ? 2 : 4;
         HIPCHK(s->xn.alloc(rows * d * as));
         HIPCHK(s->attn_out.alloc(rows * d * as));
@@ -1190,6 +1194,7 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     bool gemm_prefill = (m->wdtype == T3MI_W_F32) || s->gemm_mode;
     if (pfenv && std::strcmp(pfenv, "token") == 0) gemm_prefill = false;
     if (pfenv && std::strcmp(pfenv, "gemm") == 0) gemm_prefill = true;
+    if (s->kv_bf16) gemm_prefill = true;   // the one-position decode kernels write fp32 cache slots
     if (gemm_prefill) {
         size_t items = 0;
         for (int u = 0; u < n_utt; ++u) items += (size_t)rpu * s0[u];
@@ -1197,7 +1202,7 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         std::vector<int32_t> ipos(items), irow(items);
         std::vector<const float*> last(rows);
         size_t it = 0;
-        DevBuf xpf, qpf, xnpf, aopf, hpf, ppm, ppl, ppacc, dsrc, dpos, drow, dlast;
+        DevBuf xpf, qpf, xnpf, aopf, hpf, dsrc, dpos, drow, dlast;
         const size_t as = m->wdtype == T3MI_W_BF16 ? 2 : 4;
         HIPCHK(xpf.alloc(items * d * 4));
         for (int r = 0; r < (int)rows; ++r) {
@@ -1209,15 +1214,10 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
             }
             last[r] = xpf.as<float>() + (it - 1) * d;
         }
-        const int kps_pf = 256;
-        const int nsp_pf = (s->max_len + kps_pf - 1) / kps_pf;
         HIPCHK(qpf.alloc(items * d * 4));
         HIPCHK(xnpf.alloc(items * d * as));
         HIPCHK(aopf.alloc(items * d * as));
         HIPCHK(hpf.alloc(items * F * as));
-        HIPCHK(ppm.alloc(items * m->H * (size_t)nsp_pf * 4));
-        HIPCHK(ppl.alloc(items * m->H * (size_t)nsp_pf * 4));
-        HIPCHK(ppacc.alloc(items * m->H * (size_t)nsp_pf * 64 * 4));
         HIPCHK(dsrc.alloc(items * sizeof(void*)));
         HIPCHK(dpos.alloc(items * 4));
         HIPCHK(drow.alloc(items * 4));
@@ -1231,8 +1231,6 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         c.M = (int)items; c.x = xpf.as<float>(); c.q = qpf.as<float>();
         c.xn = xnpf.p; c.attn_out = aopf.p; c.hact = hpf.p;
         c.posmap = dpos.as<int>(); c.rowmap = drow.as<int>();
-        c.pm = ppm.as<float>(); c.pl = ppl.as<float>(); c.pacc = ppacc.as<float>();
-        c.kps = kps_pf; c.n_split = nsp_pf;
         if ((rc = run_layers_gemm(m, s.get(), c, nullptr))) return rc;
         // the last prompt position of every row feeds the first speech-head evaluation
         HIPCHK(t3k::launch_gather_rows(dlast.as<const float*>(), s->x.as<float>(), (int)rows, m->d, st));
