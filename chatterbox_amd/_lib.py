@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libt3mi.so")
+LIB_PATH = os.environ.get("T3MI_LIB", os.path.join(_HERE, "libt3mi.so"))   # T3MI_LIB: an alternative build (experiments)
 
 OK = 0
 ERR_ARG, ERR_IO, ERR_HIP, ERR_STATE = -1, -2, -3, -4

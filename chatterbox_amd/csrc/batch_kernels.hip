@@ -218,41 +218,99 @@ __global__ __launch_bounds__(KS * 64) void mfma_gemm_kernel(GemmArgs a) {
 }
 
 // ---- RMSNorm over rows: out[m] = w * (x[m] * rsqrt(mean(x[m]^2) + eps))  (R/llama.R:65-72) -------------
+// With ks > 0 the row is first completed from the K-split partial slabs of the residual GEMM before it
+// (x[m] += bias + sum_s part[s][m], s ascending; written back), which saves the separate fold launch.
+constexpr int kNormMaxPer = 8;   // d <= 2048
 template <typename AT>
-__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           float eps, AT* __restrict__ out, int d) {
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(float* __restrict__ x, const float* __restrict__ w,
+                                                           float eps, AT* __restrict__ out, int d, const float* __restrict__ part,
+                                                           int ks, const float* __restrict__ pbias, int M) {
     __shared__ float sred[4];
     const int m = blockIdx.x, tid = threadIdx.x;
-    const float* xr = x + (size_t)m * d;
+    float* xr = x + (size_t)m * d;
+    float v[kNormMaxPer];
     float ss = 0.f;
-    for (int i = tid; i < d; i += 256) ss = fmaf(xr[i], xr[i], ss);
+#pragma unroll
+    for (int j = 0; j < kNormMaxPer; ++j) {
+        const int i = tid + j * 256;
+        v[j] = 0.f;
+        if (i < d) {
+            float t = xr[i];
+            if (ks > 0) {
+                float pp[8];   // all partials requested at once, then added in order
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) pp[s2] = s2 < ks ? part[((size_t)s2 * M + m) * d + i] : 0.f;
+                float p = pp[0];
+#pragma unroll
+                for (int s2 = 1; s2 < 8; ++s2)
+                    if (s2 < ks) p += pp[s2];
+                if (pbias != nullptr) p = __fadd_rn(p, pbias[i]);
+                t = __fadd_rn(t, p);
+                xr[i] = t;
+            }
+            v[j] = t;
+            ss = fmaf(t, t, ss);
+        }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     if ((tid & 63) == 0) sred[tid >> 6] = ss;
     __syncthreads();
     const float tot = (sred[0] + sred[1]) + (sred[2] + sred[3]);
     const float rs = 1.0f / sqrtf(tot / (float)d + eps);
-    for (int i = tid; i < d; i += 256) Act<AT>::store(out + (size_t)m * d + i, __fmul_rn(w[i], __fmul_rn(xr[i], rs)));
+#pragma unroll
+    for (int j = 0; j < kNormMaxPer; ++j) {
+        const int i = tid + j * 256;
+        if (i < d) Act<AT>::store(out + (size_t)m * d + i, __fmul_rn(w[i], __fmul_rn(v[j], rs)));
+    }
 }
 
-// ---- LayerNorm over rows (Turbo, R/t3.R:1200-1203): two-pass mean / biased variance -------------------------
+// ---- LayerNorm over rows (Turbo, R/t3.R:1200-1203): two-pass mean / biased variance; same optional fold ------
 template <typename AT>
-__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             const float* __restrict__ b, float eps, AT* __restrict__ out, int d) {
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, float eps, AT* __restrict__ out, int d,
+                                                             const float* __restrict__ part, int ks, const float* __restrict__ pbias,
+                                                             int M) {
     __shared__ float sred[8];
     const int m = blockIdx.x, tid = threadIdx.x;
-    const float* xr = x + (size_t)m * d;
+    float* xr = x + (size_t)m * d;
+    float v[kNormMaxPer];
     float sm = 0.f;
-    for (int i = tid; i < d; i += 256) sm += xr[i];
+#pragma unroll
+    for (int j = 0; j < kNormMaxPer; ++j) {
+        const int i = tid + j * 256;
+        v[j] = 0.f;
+        if (i < d) {
+            float t = xr[i];
+            if (ks > 0) {
+                float pp[8];   // all partials requested at once, then added in order
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) pp[s2] = s2 < ks ? part[((size_t)s2 * M + m) * d + i] : 0.f;
+                float p = pp[0];
+#pragma unroll
+                for (int s2 = 1; s2 < 8; ++s2)
+                    if (s2 < ks) p += pp[s2];
+                if (pbias != nullptr) p = __fadd_rn(p, pbias[i]);
+                t = __fadd_rn(t, p);
+                xr[i] = t;
+            }
+            v[j] = t;
+            sm += t;
+        }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
     if ((tid & 63) == 0) sred[tid >> 6] = sm;
     __syncthreads();
     const float mean = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / (float)d;
     float ss = 0.f;
-    for (int i = tid; i < d; i += 256) {
-        const float c = xr[i] - mean;
-        ss = fmaf(c, c, ss);
+#pragma unroll
+    for (int j = 0; j < kNormMaxPer; ++j) {
+        const int i = tid + j * 256;
+        if (i < d) {
+            const float c = v[j] - mean;
+            ss = fmaf(c, c, ss);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
@@ -260,8 +318,11 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
     __syncthreads();
     const float var = ((sred[4] + sred[5]) + (sred[6] + sred[7])) / (float)d;
     const float rs = 1.0f / sqrtf(var + eps);
-    for (int i = tid; i < d; i += 256)
-        Act<AT>::store(out + (size_t)m * d + i, __fadd_rn(__fmul_rn(__fmul_rn(xr[i] - mean, rs), w[i]), b[i]));
+#pragma unroll
+    for (int j = 0; j < kNormMaxPer; ++j) {
+        const int i = tid + j * 256;
+        if (i < d) Act<AT>::store(out + (size_t)m * d + i, __fadd_rn(__fmul_rn(__fmul_rn(v[j] - mean, rs), w[i]), b[i]));
+    }
 }
 
 // ---- merge of the split-softmax attention partials into the o_proj activation rows ----------------------
@@ -642,7 +703,9 @@ hipError_t launch_gemm_rows_bf16(const GemmArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL(gemm_rows_bf16_kernel<EPI>, dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     hipError_t e = hipGetLastError();
+    if (a.ks_out != nullptr) *a.ks_out = ks;
     if (e != hipSuccess || ks == 1) return e;
+    if (a.ks_out != nullptr && EPI == EPI_RESID && a.resid == a.y) return e;   // the caller folds (fused into its norm launch)
     hipLaunchKernelGGL(fold_partials_kernel, dim3(a.M, (a.N + 255) / 256), dim3(256), 0, s, a.y, EPI == EPI_RESID ? a.resid : nullptr, a.part, ks,
                        a.bias, a.M, a.N, a.ldy);
     return hipGetLastError();
@@ -718,23 +781,33 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
     return wdtype == 1 ? launch_gemm_g<GemmBF16>(a, epilogue, s) : launch_gemm_g<GemmF32>(a, epilogue, s);
 }
 
-hipError_t launch_rmsnorm_rows(const float* x, const float* w, float eps, void* out, int M, int d, int act_bf16,
-                               hipStream_t s) {
-    if (!x || !w || !out || M <= 0 || d <= 0) return hipErrorInvalidValue;
+hipError_t launch_rmsnorm_rows(float* x, const float* w, float eps, void* out, int M, int d, int act_bf16, hipStream_t s,
+                               const float* part, int ks, const float* pbias) {
+    if (!x || !w || !out || M <= 0 || d <= 0 || d > 256 * kNormMaxPer || (ks > 0 && !part)) return hipErrorInvalidValue;
     if (act_bf16)
-        hipLaunchKernelGGL(rmsnorm_rows_kernel<uint16_t>, dim3(M), dim3(256), 0, s, x, w, eps, static_cast<uint16_t*>(out), d);
+        hipLaunchKernelGGL(rmsnorm_rows_kernel<uint16_t>, dim3(M), dim3(256), 0, s, x, w, eps, static_cast<uint16_t*>(out), d, part,
+                           ks, pbias, M);
     else
-        hipLaunchKernelGGL(rmsnorm_rows_kernel<float>, dim3(M), dim3(256), 0, s, x, w, eps, static_cast<float*>(out), d);
+        hipLaunchKernelGGL(rmsnorm_rows_kernel<float>, dim3(M), dim3(256), 0, s, x, w, eps, static_cast<float*>(out), d, part, ks,
+                           pbias, M);
     return hipGetLastError();
 }
 
-hipError_t launch_layernorm_rows(const float* x, const float* w, const float* b, float eps, void* out, int M, int d,
-                                 int act_bf16, hipStream_t s) {
-    if (!x || !w || !b || !out || M <= 0 || d <= 0) return hipErrorInvalidValue;
+hipError_t launch_layernorm_rows(float* x, const float* w, const float* b, float eps, void* out, int M, int d, int act_bf16,
+                                 hipStream_t s, const float* part, int ks, const float* pbias) {
+    if (!x || !w || !b || !out || M <= 0 || d <= 0 || d > 256 * kNormMaxPer || (ks > 0 && !part)) return hipErrorInvalidValue;
     if (act_bf16)
-        hipLaunchKernelGGL(layernorm_rows_kernel<uint16_t>, dim3(M), dim3(256), 0, s, x, w, b, eps, static_cast<uint16_t*>(out), d);
+        hipLaunchKernelGGL(layernorm_rows_kernel<uint16_t>, dim3(M), dim3(256), 0, s, x, w, b, eps, static_cast<uint16_t*>(out), d,
+                           part, ks, pbias, M);
     else
-        hipLaunchKernelGGL(layernorm_rows_kernel<float>, dim3(M), dim3(256), 0, s, x, w, b, eps, static_cast<float*>(out), d);
+        hipLaunchKernelGGL(layernorm_rows_kernel<float>, dim3(M), dim3(256), 0, s, x, w, b, eps, static_cast<float*>(out), d, part,
+                           ks, pbias, M);
+    return hipGetLastError();
+}
+
+hipError_t launch_fold_partials(float* x, const float* part, int ks, const float* pbias, int M, int d, hipStream_t s) {
+    if (!x || !part || ks < 1 || M <= 0 || d <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(M, (d + 255) / 256), dim3(256), 0, s, x, x, part, ks, pbias, M, d, d);
     return hipGetLastError();
 }
 

@@ -108,11 +108,15 @@ struct BF16W {
 //   SWIGLU      : gate rows and the matching up rows (F = N/2 apart)
 // launch counter of the decode chain, read by the L2 prefetcher as a throttle (a hint: never a data hand-off)
 __device__ __forceinline__ void bump_progress(int* p) {
+#ifdef T3K_PREFETCH_EXPERIMENTS
     if (p != nullptr) {
         const int old = __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // diagnostic (T3MI_PF_DEBUG): the hardware XCD block 0 of launch number `old` ran on
         if (p[kPfLogOn]) p[kPfXccLog + (old & 1023)] = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u);
     }
+#else
+    (void)p;
+#endif
 }
 
 template <int EPI, int ROWS>
@@ -150,16 +154,6 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
 
     [[maybe_unused]] const int gwave = (int)blockIdx.x * nw + wave;
     T3K_STAMP(a, gwave, 0);
-    // Every argument the kernel reads, requested from the kernarg segment in ONE batch of scalar loads.  Left to
-    // itself the compiler loads each field next to its first use behind a wait of its own: six dependent kernarg round
-    // trips ahead of the first weight load (each a scalar-cache miss on a fresh launch) instead of one.
-    asm volatile("" ::"s"(a.W), "s"(a.x), "s"(a.ln_w), "s"(a.bias), "s"(a.y), "s"(a.resid), "s"(a.rowpos), "s"(a.rope_cur),
-                 "s"(a.kcache), "s"(a.vcache), "s"(a.pm), "s"(a.pl), "s"(a.pacc), "s"(a.eps), "s"(a.N), "s"(a.ldy),
-                 "s"(a.n_heads), "s"(a.max_len), "s"(a.n_split_max), "s"(a.keys_per_split), "s"(a.rope), "s"(n_chunks),
-                 "s"(a.pf[0].item.W), "s"(a.pf[1].item.W), "s"(a.progress));
-#ifdef T3K_STAMPS_KERNARG
-    T3K_STAMP(a, gwave, 5);   // experiment: kernel arguments landed
-#endif
     if (blockIdx.x == 0 && tid == 0) bump_progress(a.progress);
 
     // ---- 1. small L2-resident operands FIRST.  Vector-memory results return in issue order, so anything
@@ -261,6 +255,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
     if (c < n_chunks) load_chunk(c);
     T3K_STAMP(a, gwave, 7);   // every load of the first chunk issued (nothing waited for yet)
 
+#ifdef T3K_PREFETCH_EXPERIMENTS
     // ---- 2b. L2 prefetch for later launches.  A batch-1 decode kernel streams only a few MB, so its fixed ramp
     // (first-byte latency, tail) dominates; the weights of the NEXT launches do not depend on this launch's result,
     // so every wave touches one dword per 128-byte line of its share of them, from a block on the XCD whose L2 the
@@ -319,8 +314,10 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
         }
     }
 
+#endif
+
     // ---- 3. prologue math while the weights are in flight
-#if defined(T3K_STAMPS) && !defined(T3K_STAMPS_KERNARG)
+#ifdef T3K_STAMPS
     if (PRO == PRO_NORM) {
         asm volatile("" ::"v"(vx[0][0].x));
         T3K_STAMP(a, gwave, 5);   // this wave's x slices landed
@@ -649,6 +646,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
         }
     }
     T3K_STAMP(a, gwave, 4);   // stores issued
+#ifdef T3K_PREFETCH_EXPERIMENTS
     {
         // keeps the prefetch loads alive; N is never negative (checked at launch), the compiler cannot know it
         float t = 0.f;
@@ -658,6 +656,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
             for (int u = 0; u < kPfMax; ++u) t += pfv[jb][u];
         if (a.N < 0) a.y[0] = t;
     }
+#endif
 }
 
 // ---- single-query attention over the KV cache, split along the keys ---------------------------------

@@ -121,6 +121,8 @@ struct GemmArgs {
     int n_heads = 0, max_len = 0;
     float* part = nullptr;        // scratch for K-split partial sums (EPI_STORE / EPI_RESID), or nullptr: no split
     size_t part_floats = 0;
+    int* ks_out = nullptr;        // host: receives the K-split factor; with it set a residual GEMM in place (y == resid)
+                                  // leaves the fold of its partial slabs to the caller (launch_*norm_rows / launch_fold_partials)
     unsigned long long* dbg = nullptr;  // diagnostic (scripts/micro/gemm_micro.cpp): [block][4] clock stamps, or nullptr
 };
 
@@ -176,10 +178,13 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t s);
 hipError_t launch_prefill_embed(const EmbedArgs& a, hipStream_t s);
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t s);
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t s);
-hipError_t launch_layernorm_rows(const float* x, const float* w, const float* b, float eps, void* out, int M, int d,
-                                 int act_bf16, hipStream_t s);
-hipError_t launch_rmsnorm_rows(const float* x, const float* w, float eps, void* out, int M, int d, int act_bf16,
-                               hipStream_t s);
+// row norms of the many-row path; with ks > 0 they first complete x from the K-split partial slabs of the residual
+// GEMM before them: x[m] += pbias + sum_s part[s][m] (written back)
+hipError_t launch_layernorm_rows(float* x, const float* w, const float* b, float eps, void* out, int M, int d, int act_bf16,
+                                 hipStream_t s, const float* part = nullptr, int ks = 0, const float* pbias = nullptr);
+hipError_t launch_rmsnorm_rows(float* x, const float* w, float eps, void* out, int M, int d, int act_bf16, hipStream_t s,
+                               const float* part = nullptr, int ks = 0, const float* pbias = nullptr);
+hipError_t launch_fold_partials(float* x, const float* part, int ks, const float* pbias, int M, int d, hipStream_t s);
 hipError_t launch_attn_merge(const float* pm, const float* pl, const float* pacc, const int* posmap, void* out, int M,
                              int H, int n_split_max, int kps, int act_bf16, hipStream_t s);
 // many-row attention (batched decode, prefill): one block per (query item, head) over keys 0..posmap[item]; writes

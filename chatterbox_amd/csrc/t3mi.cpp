@@ -82,6 +82,8 @@ struct Session {
     bool gemm_mode = false;     // > 4 activation rows: linears run as MFMA GEMMs (batch_kernels.hip)
     bool kv_bf16 = false;       // KV slabs hold bf16 (many-row regime with bf16 weights), else fp32
     DevBuf gpart;               // GEMM-path K-split partial sums: [<= 8][rows][d] fp32
+    int pend_ks = 0;            // the decode step's last down_proj left its fold to the head's norm launch
+    const float* pend_bias = nullptr;
     DevBuf xn, attn_out, hact;  // GEMM-path activation rows (float with fp32 weights, bf16 with bf16 weights)
     t3mi_params prm{};
     std::vector<int32_t> s0;
@@ -616,9 +618,12 @@ struct GemmCtx {
     const int* rowmap = nullptr;
     float *pm = nullptr, *pl = nullptr, *pacc = nullptr;
     int kps = 64, n_split = 1;
+    // K-split residual GEMM whose partial slabs are still to be folded into x (by the next norm launch)
+    int pend_ks = 0;
+    const float* pend_bias = nullptr;
 };
 
-int run_layers_gemm(t3mi_model* m, Session* s, const GemmCtx& c, StepTimer* tm) {
+int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
     const int d = m->d, F = m->F, H = m->H;
     const int abf = m->wdtype == T3MI_W_BF16 ? 1 : 0;
     const bool turbo = m->variant == T3MI_VARIANT_TURBO;
@@ -628,8 +633,10 @@ int run_layers_gemm(t3mi_model* m, Session* s, const GemmCtx& c, StepTimer* tm) 
         const LayerW& lw = m->layers[l];
         char* kc = s->kc.as<char>() + layer_kv * l;
         char* vc = s->vc.as<char>() + layer_kv * l;
-        if (turbo) HIPCHK(t3k::launch_layernorm_rows(c.x, lw.ln1, lw.ln1_b, m->eps, c.xn, c.M, d, abf, st));
-        else HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln1, m->eps, c.xn, c.M, d, abf, st));
+        const float* gp = s->gpart.as<float>();
+        if (turbo) HIPCHK(t3k::launch_layernorm_rows(c.x, lw.ln1, lw.ln1_b, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias));
+        else HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln1, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias));
+        c.pend_ks = 0;
         {
             t3k::GemmArgs a;
             a.W = lw.wqkv; a.A = c.xn; a.M = c.M; a.N = 3 * d; a.K = d;
@@ -653,11 +660,16 @@ int run_layers_gemm(t3mi_model* m, Session* s, const GemmCtx& c, StepTimer* tm) 
             a.W = lw.wo; a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
             a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_o;
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
+            int ks = 1;
+            a.ks_out = &ks;
             HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, m->wdtype, st));
+            c.pend_ks = ks > 1 ? ks : 0;
+            c.pend_bias = lw.b_o;
         }
         if (tm) tm->mark(K_OPROJ);
-        if (turbo) HIPCHK(t3k::launch_layernorm_rows(c.x, lw.ln2, lw.ln2_b, m->eps, c.xn, c.M, d, abf, st));
-        else HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln2, m->eps, c.xn, c.M, d, abf, st));
+        if (turbo) HIPCHK(t3k::launch_layernorm_rows(c.x, lw.ln2, lw.ln2_b, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias));
+        else HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln2, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias));
+        c.pend_ks = 0;
         {
             t3k::GemmArgs a;
             a.W = lw.wgu; a.A = c.xn; a.M = c.M; a.N = turbo ? F : 2 * F; a.K = d; a.yact = c.hact;
@@ -670,10 +682,20 @@ int run_layers_gemm(t3mi_model* m, Session* s, const GemmCtx& c, StepTimer* tm) 
             a.W = lw.wdown; a.A = c.hact; a.M = c.M; a.N = d; a.K = F;
             a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_down;
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
+            int ks = 1;
+            a.ks_out = &ks;
             HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, m->wdtype, st));
+            c.pend_ks = ks > 1 ? ks : 0;
+            c.pend_bias = lw.b_down;
         }
         if (tm) tm->mark(K_DOWN);
     }
+    return T3MI_OK;   // c.pend_ks > 0: the last down_proj is still to be folded (run_head's norm, or fold_pending)
+}
+
+int fold_pending(t3mi_model* m, Session* s, GemmCtx& c) {
+    if (c.pend_ks > 0) HIPCHK(t3k::launch_fold_partials(c.x, s->gpart.as<float>(), c.pend_ks, c.pend_bias, c.M, m->d, m->stream));
+    c.pend_ks = 0;
     return T3MI_OK;
 }
 
@@ -694,8 +716,11 @@ int run_head(t3mi_model* m, Session* s, StepTimer* tm) {
         const int abf = m->wdtype == T3MI_W_BF16 ? 1 : 0;
         if (turbo)
             HIPCHK(t3k::launch_layernorm_rows(s->x.as<float>(), m->norm_w, m->norm_b, m->eps, s->xn.p, s->rows, d, abf,
-                                              m->stream));
-        else HIPCHK(t3k::launch_rmsnorm_rows(s->x.as<float>(), m->norm_w, m->eps, s->xn.p, s->rows, d, abf, m->stream));
+                                              m->stream, s->gpart.as<float>(), s->pend_ks, s->pend_bias));
+        else
+            HIPCHK(t3k::launch_rmsnorm_rows(s->x.as<float>(), m->norm_w, m->eps, s->xn.p, s->rows, d, abf, m->stream,
+                                            s->gpart.as<float>(), s->pend_ks, s->pend_bias));
+        s->pend_ks = 0;
         t3k::GemmArgs a;
         a.W = m->head_w; a.A = s->xn.p; a.M = s->rows; a.N = m->V; a.K = d;
         a.y = s->logits.as<float>(); a.ldy = m->V; a.bias = m->head_b;
@@ -755,7 +780,12 @@ int run_decode_step(t3mi_model* m, Session* s, StepTimer* tm) {
     s->li = 0;
     s->in_step = true;
     if (!(rc = run_sampler(m, s, tm))) {
-        if (s->gemm_mode) rc = run_layers_gemm(m, s, decode_ctx(s), tm);
+        if (s->gemm_mode) {
+            GemmCtx c = decode_ctx(s);
+            rc = run_layers_gemm(m, s, c, tm);
+            s->pend_ks = c.pend_ks;
+            s->pend_bias = c.pend_bias;
+        }
         else rc = run_layers(m, s, tm);
     }
     if (!rc) rc = run_head(m, s, tm);
@@ -947,10 +977,16 @@ int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model*
         for (int q = 0; q < 8; ++q) ok = ok && cnt[q] == 32;
         const char* pe = std::getenv("T3MI_PREFETCH");
         m->pf_ok = ok && pe && pe[0] == '1';   // experiment, off by default: measured slower
+#ifndef T3K_PREFETCH_EXPERIMENTS
+        m->pf_ok = false;                      // the kernels carry the hooks only in a -DT3K_PREFETCH_EXPERIMENTS build
+#endif
         HIPCHK(hipMemcpy(m->pf_state.p, st, stv.size() * 4, hipMemcpyHostToDevice));
         if (const char* v = std::getenv("T3MI_PF_LOOKAHEAD")) m->pf_lookahead = std::max(1, std::atoi(v));
         if (const char* v = std::getenv("T3MI_IKPF")) m->ikpf_ok = v[0] == '1';
         m->ikpf_ok = m->ikpf_ok && ok;   // needs the same block -> XCD placement in every launch
+#ifndef T3K_PREFETCH_EXPERIMENTS
+        m->ikpf_ok = false;
+#endif
         if (const char* v = std::getenv("T3MI_IKPF_SPLIT")) m->ikpf_split16 = std::min(16, std::max(0, std::atoi(v)));
         if (const char* v = std::getenv("T3MI_IKPF_BIG_MB")) m->ikpf_big_mb = std::max(1, std::atoi(v));
         if (const char* v = std::getenv("T3MI_PF_MODE")) m->pf_max_polls |= (std::atoi(v) & 3) << 24;
@@ -1232,6 +1268,7 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         c.xn = xnpf.p; c.attn_out = aopf.p; c.hact = hpf.p;
         c.posmap = dpos.as<int>(); c.rowmap = drow.as<int>();
         if ((rc = run_layers_gemm(m, s.get(), c, nullptr))) return rc;
+        if ((rc = fold_pending(m, s.get(), c))) return rc;
         // the last prompt position of every row feeds the first speech-head evaluation
         HIPCHK(t3k::launch_gather_rows(dlast.as<const float*>(), s->x.as<float>(), (int)rows, m->d, st));
         HIPCHK(hipStreamSynchronize(st));  // host vectors and the prefill scratch die here
