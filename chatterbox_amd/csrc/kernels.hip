@@ -134,7 +134,13 @@ __device__ __forceinline__ int chunk_row(int c, int j, int N) {
 }
 
 template <typename WT, int R, int NK, int KSPLIT, int ROWS, int EPI, int PRO>
-__global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
+// The operands every wave needs before it can issue its first load come first in the signature as plain scalars, so
+// that a build with -mllvm -amdgpu-kernarg-preload-count (Makefile: PRELOAD) receives them in SGPRs at wave launch
+// instead of through a kernarg round trip (0.4-0.5 us in the stamp timeline); on the replayed-graph bench the two
+// builds measure the same.
+__global__ __launch_bounds__(512) void gemv_kernel(const void* __restrict__ pW, const float* __restrict__ px, const float* __restrict__ pln_w,
+                                                   const float* presid, const int* __restrict__ prowpos,
+                                                   const float* __restrict__ prope_cur, int pN, int n_chunks, GemvArgs a) {
     constexpr int E = WT::E;
     constexpr int KW = NK * kWave * E;  // K elements handled by one wave
     constexpr int K = KW * KSPLIT;
@@ -167,20 +173,20 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
         if (EPI == EPI_ROPE_KV) {
             if (lane < HP * R) {
                 const int r = lane % R;
-                e_pos = a.rowpos[r];
+                e_pos = prowpos[r];
                 if (c < n_chunks) {
                     const int per_head = 32 / HP;
                     const int i = (c % per_head) * HP + lane / R;   // rotate_half pair index 0..31
                     // rope_cur[r] = cos/sin rows of row r's CURRENT position, staged by the sampler / prefill
                     // kernel so that this load does not wait for rowpos (cos[i] == cos[i+32]: emb = cat(freqs, freqs))
-                    e_c = a.rope_cur[(size_t)(2 * r) * kHeadDim + i];
-                    e_s = a.rope_cur[(size_t)(2 * r + 1) * kHeadDim + i];
+                    e_c = prope_cur[(size_t)(2 * r) * kHeadDim + i];
+                    e_s = prope_cur[(size_t)(2 * r + 1) * kHeadDim + i];
                 }
             }
         } else if (EPI == EPI_RESID) {
             if (lane < ROWS * R && c < n_chunks && (KSPLIT == 1 || kpart == 0)) {
                 const int n = ROWS * c + lane / R;
-                if (n < a.N) e_res = a.resid[(size_t)(lane % R) * a.ldy + n];
+                if (n < pN) e_res = presid[(size_t)(lane % R) * a.ldy + n];
             }
         }
     }
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
             const bool ok = idx < R * (K / 4);
             const int r = ok ? idx / (K / 4) : 0, k4 = ok ? idx % (K / 4) : 0;
             const int head = k4 >> 4, dd = (k4 & 15) << 2;
-            a_pos[it] = ok ? a.rowpos[r] : -1;
+            a_pos[it] = ok ? prowpos[r] : -1;
             const size_t b = ((size_t)r * H + head) * a.n_split_max;
 #pragma unroll
             for (int sp = 0; sp < SPC; ++sp) {
@@ -224,8 +230,8 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
             const int i = (tid + j * nthr) * 4;
             if (i < K) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) vx[r][j] = *reinterpret_cast<const float4*>(a.x + (size_t)r * K + i);
-                gx[j] = *reinterpret_cast<const float4*>(a.ln_w + i);
+                for (int r = 0; r < R; ++r) vx[r][j] = *reinterpret_cast<const float4*>(px + (size_t)r * K + i);
+                gx[j] = *reinterpret_cast<const float4*>(pln_w + i);
             }
         }
     } else {
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
             for (int q = 0; q < NK; ++q)
 #pragma unroll
                 for (int e4 = 0; e4 < E; e4 += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(a.x + (size_t)r * K + kbase + q * kWave * E + lane * E + e4);
+                    const float4 v = *reinterpret_cast<const float4*>(px + (size_t)r * K + kbase + q * kWave * E + lane * E + e4);
                     xv[r][q][e4 + 0] = v.x; xv[r][q][e4 + 1] = v.y; xv[r][q][e4 + 2] = v.z; xv[r][q][e4 + 3] = v.w;
                 }
     }
@@ -245,11 +251,11 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
     auto load_chunk = [&](int cc) {
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
-            int row = chunk_row<EPI, ROWS>(cc, j, a.N);
-            row = row < a.N ? row : a.N - 1;
+            int row = chunk_row<EPI, ROWS>(cc, j, pN);
+            row = row < pN ? row : pN - 1;
             const size_t off = (size_t)row * K + kbase + lane * E;
 #pragma unroll
-            for (int q = 0; q < NK; ++q) WT::load(a.W, off + (size_t)q * kWave * E, w[j][q]);
+            for (int q = 0; q < NK; ++q) WT::load(pW, off + (size_t)q * kWave * E, w[j][q]);
         }
     };
     if (c < n_chunks) load_chunk(c);
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
                 for (int r = 0; r < R; ++r)
                     if (lane == j * R + r) {
                         const int n = ROWS * c + j;
-                        if (n < a.N) {
+                        if (n < pN) {
                             float v = acc[j][r];
                             if (a.bias != nullptr) v = __fadd_rn(v, a.bias[n]);
                             const float inner = 0.7978845608028654f * (v + 0.044715f * v * v * v);
@@ -580,12 +586,12 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
                 for (int r = 0; r < R; ++r)
                     if (lane == j * R + r) {
                         const int n = ROWS * c + j;
-                        if (n < a.N) {
+                        if (n < pN) {
                             const size_t o = (size_t)r * a.ldy + n;
                             float v = acc[j][r];
                             if (a.bias != nullptr) v = __fadd_rn(v, a.bias[n]);
                             if (EPI == EPI_RESID) {
-                                const float res = first ? e_res : a.resid[o];
+                                const float res = first ? e_res : presid[o];
                                 a.y[o] = __fadd_rn(res, v);
                             } else {
                                 a.y[o] = v;
@@ -627,8 +633,8 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
                             if (kind < 2 && a.rope) {
                                 // q*cos + rotate_half(q)*sin, each product rounded (R/llama.R:184-185);
                                 // cos/sin rows repeat with period 32, so one (cos, sin) serves both halves
-                                const float cs = first ? e_c : a.rope_cur[(size_t)(2 * r) * kHeadDim + i];
-                                const float sn = first ? e_s : a.rope_cur[(size_t)(2 * r + 1) * kHeadDim + i];
+                                const float cs = first ? e_c : prope_cur[(size_t)(2 * r) * kHeadDim + i];
+                                const float sn = first ? e_s : prope_cur[(size_t)(2 * r + 1) * kHeadDim + i];
                                 const float nlo = __fadd_rn(__fmul_rn(lo, cs), __fmul_rn(-hi, sn));
                                 const float nhi = __fadd_rn(__fmul_rn(hi, cs), __fmul_rn(lo, sn));
                                 lo = nlo; hi = nhi;
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int n_chunks) {
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
             for (int u = 0; u < kPfMax; ++u) t += pfv[jb][u];
-        if (a.N < 0) a.y[0] = t;
+        if (pN < 0) a.y[0] = t;
     }
 #endif
 }
@@ -1315,7 +1321,7 @@ hipError_t launch_gemv_t(const GemvArgs& a, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(nw * 64), lds, s, a, n_chunks);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(nw * 64), lds, s, a.W, a.x, a.ln_w, a.resid, a.rowpos, a.rope_cur, a.N, n_chunks, a);
     return hipGetLastError();
 }
 
