@@ -184,6 +184,9 @@ def main():
                 for k in sess.profile_step():
                     a = acc.setdefault(k["name"], dict(launches=k["launches"], us=0.0, bytes=k["bytes"]))
                     a["us"] += k["total_us"] / reps
+            roof["per_kernel_note"] = ("eager launches bracketed by HIP events, one step at a time: each figure includes the "
+                                       "launch gap, so they sum to more than avg_launch_us of the replayed graph; the "
+                                       "in-graph kernel durations are in profiles/r01_kernel_stats.csv")
             roof["per_kernel"] = [
                 {"name": n, "launches_per_step": a["launches"], "avg_us": round(a["us"] / max(a["launches"], 1), 2),
                  "GB/s": round(a["bytes"] / max(a["us"], 1e-9) / 1e3, 1)} for n, a in acc.items()]
