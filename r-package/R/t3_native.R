@@ -7,12 +7,13 @@
 .t3mi <- new.env(parent = emptyenv())
 
 #' Open (once) the native model for the safetensors file the R model was loaded from.
-t3mi_model <- function (path, device = 0L, dtype = c("f32", "bf16"))
+t3mi_model <- function (path, device = 0L, dtype = c("f32", "bf16"), variant = c("llama", "turbo"))
 {
     dtype <- match.arg(dtype)
-    key <- paste(normalizePath(path), device, dtype)
+    variant <- match.arg(variant)
+    key <- paste(normalizePath(path), device, dtype, variant)
     if (is.null(.t3mi[[key]])) {
-        .t3mi[[key]] <- .Call("t3mi_r_open", path, 0L, as.integer(device),
+        .t3mi[[key]] <- .Call("t3mi_r_open", path, if (variant == "turbo") 1L else 0L, as.integer(device),
                               if (dtype == "bf16") 1L else 0L, PACKAGE = "chatterbox")
     }
     .t3mi[[key]]
@@ -75,4 +76,34 @@ t3_inference_cpp <- function (model, cond, text_tokens, max_new_tokens = 1000,
     }
     if (length(ids) > 0L) torch::torch_tensor(ids, dtype = torch::torch_long(), device = r$device)
     else torch::torch_tensor(integer(0), device = r$device)
+}
+
+#' Same signature and return value as t3_inference_turbo (R/t3.R:1578-1580, 1662-1676): GPT-2 backbone, no CFG,
+#' top-k / top-p logit processors; the trailing stop token is removed.
+t3_inference_turbo <- function (model, cond, text_tokens, max_new_tokens = 1000,
+                                temperature = 0.8, top_k = 1000L, top_p = 0.95,
+                                repetition_penalty = 1.2,
+                                native = t3mi_model(attr(model, "t3_path"), variant = "turbo"))
+{
+    config <- model$config
+    device <- model$speech_emb$weight$device
+    if (text_tokens$dim() == 1L) text_tokens <- text_tokens$unsqueeze(1L)
+    speech_start <- torch::torch_tensor(matrix(config$start_speech_token, nrow = 1L), device = device,
+                                        dtype = torch::torch_long())
+    # prompt construction stays in R torch until SURVEY f1 lands (R/t3.R:1599)
+    embeds <- torch::with_no_grad(model$prepare_input_embeds(cond, text_tokens, speech_start)$embeds)
+    e <- as.array(embeds$to(device = "cpu", dtype = torch::torch_float32()))   # [1, S0, d]
+    cfg <- list(max_tokens = as.integer(max_new_tokens), temperature = as.double(temperature),
+                cfg_weight = 0, top_k = as.integer(top_k), top_p = as.double(top_p), min_p = 0,
+                rep_penalty = as.double(repetition_penalty), sampler = 2L,
+                start_token = as.integer(config$start_speech_token),
+                stop_token = as.integer(config$stop_speech_token))
+    ids <- .Call("t3mi_r_generate", native, e, as.integer(dim(e)), cfg, PACKAGE = "chatterbox")
+    n <- length(ids)
+    if (n > 0L && ids[n] == config$stop_speech_token) {
+        message("EOS at step ", n)
+        ids <- ids[seq_len(n - 1L)]
+    }
+    if (length(ids) > 0L) torch::torch_tensor(ids, dtype = torch::torch_long(), device = device)
+    else torch::torch_tensor(integer(0), device = device)
 }

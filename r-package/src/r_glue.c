@@ -71,6 +71,7 @@ static void fill_params(SEXP cfg, t3mi_params* p) {
     p->stop_token = (int32_t)cfg_real(cfg, "stop_token", 6562, 1);
     p->start_token = (int32_t)cfg_real(cfg, "start_token", 6561, 0);
     p->sampler = (int32_t)cfg_real(cfg, "sampler", T3MI_SAMPLER_R, 0);
+    p->top_k = (int32_t)cfg_real(cfg, "top_k", 0, 0);                 /* Turbo (.turbo_sample_token, R/t3.R:1688-1742) */
     p->max_cache_len = (int32_t)cfg_real(cfg, "max_cache_len", 0, 0);
     p->seed = (uint64_t)cfg_real(cfg, "seed", 0, 0);
 }
@@ -99,7 +100,7 @@ SEXP t3mi_r_generate(SEXP model, SEXP embeds, SEXP dims, SEXP cfg) {
     t3mi_params p;
     fill_params(cfg, &p);
     float* e = to_row_major(embeds, rows, s0, d);
-    const int cap = p.max_new_tokens > 0 ? p.max_new_tokens : 1;
+    const int cap = (p.max_new_tokens > 0 ? p.max_new_tokens : 1) + 1;   /* Turbo returns up to max_tokens + 1 ids */
     int32_t* out = (int32_t*)malloc((size_t)cap * sizeof(int32_t));
     int32_t n = 0;
     int rc = out ? t3mi_generate(m, e, rows, s0, &p, out, cap, &n) : T3MI_ERR_ARG;
@@ -128,7 +129,7 @@ SEXP t3mi_r_generate_batch(SEXP model, SEXP embeds_list, SEXP dims, SEXP cfg) {
     const int rows = dm[0], d = dm[2 * n_utt];
     float** e = (float**)calloc((size_t)n_utt, sizeof(float*));
     int32_t* s0 = (int32_t*)malloc((size_t)n_utt * sizeof(int32_t));
-    const int cap = p.max_new_tokens > 0 ? p.max_new_tokens : 1;
+    const int cap = (p.max_new_tokens > 0 ? p.max_new_tokens : 1) + 1;   /* Turbo returns up to max_tokens + 1 ids */
     int32_t* out = (int32_t*)malloc((size_t)n_utt * cap * sizeof(int32_t));
     int32_t* n_out = (int32_t*)calloc((size_t)n_utt, sizeof(int32_t));
     int rc = T3MI_OK;
