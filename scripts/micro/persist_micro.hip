@@ -163,6 +163,11 @@ __device__ __forceinline__ void poison(float* g, int gstride, const Ctx& c) {
 #define LOG(e, k) do { if (c.comm && c.b == kLogWG && c.lane == 0) c.bf.log[(l * 5 + (e)) * 3 + (k)] = wall_clock64(); } while (0)
 #define DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
+#ifdef PUBLISH_FIRST
+#define BAR3() BAR()   // third barrier per edge: the publish stores are issued before the next slab's loads
+#else
+#define BAR3()
+#endif
 #define BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // The two kinds of wave run separate loops with the same sequence of barriers (two per edge), so the register
@@ -173,15 +178,26 @@ __device__ __forceinline__ void layer_compute(f4 (&A)[8], f4 (&B)[8], f4 (&C)[8]
     const Bufs& bf = c.bf;
     const size_t Wl = (size_t)l * kLayerFloats, Wn = Wl + kLayerFloats;
     const bool more = l + 1 < bf.layers;
-    BAR(); consume<P0, 0>(A, c, 0); BAR();
+#ifdef DEFER_ISSUE
+    // a freed slab is re-issued only after the NEXT edge's input has arrived, so the communication wave's polling loads
+    // never queue behind a fresh slab in this CU's memory pipeline
+    BAR(); if (l > 0) issue<P4, 0>(D, Wl + kO4, c); consume<P0, 0>(A, c, 0); BAR(); BAR3();
+    BAR(); issue<P5, 0>(A, Wl + kO5, c); consume<P1, 0>(B, c, 0); BAR(); BAR3();
+    BAR(); consume<P2, 2>(B, c, 0); BAR(); BAR3();
+    BAR(); if (more) issue<P0, 0>(B, Wn, c); consume<P3, 0>(C, c, 0); consume<P4, 0>(D, c, 1); BAR(); BAR3();
+    BAR(); if (more) { issue<P1, 0>(C, Wn + kO1, c); issue<P2, 2>(C, Wn + kO2, c); issue<P3, 0>(D, Wn + kO3, c); }
+    consume<P5, 0>(A, c, 0); BAR(); BAR3();
+#else
+    BAR(); consume<P0, 0>(A, c, 0); BAR(); BAR3();
     issue<P5, 0>(A, Wl + kO5, c);
-    BAR(); consume<P1, 0>(B, c, 0); BAR();
-    BAR(); consume<P2, 2>(B, c, 0); BAR();
+    BAR(); consume<P1, 0>(B, c, 0); BAR(); BAR3();
+    BAR(); consume<P2, 2>(B, c, 0); BAR(); BAR3();
     if (more) issue<P0, 0>(B, Wn, c);
-    BAR(); consume<P3, 0>(C, c, 0); consume<P4, 0>(D, c, 1); BAR();
+    BAR(); consume<P3, 0>(C, c, 0); consume<P4, 0>(D, c, 1); BAR(); BAR3();
     if (more) { issue<P1, 0>(C, Wn + kO1, c); issue<P2, 2>(C, Wn + kO2, c); issue<P3, 0>(D, Wn + kO3, c); }
-    BAR(); consume<P5, 0>(A, c, 0); BAR();
+    BAR(); consume<P5, 0>(A, c, 0); BAR(); BAR3();
     if (more) issue<P4, 0>(A, Wn + kO4, c);
+#endif
 }
 
 // Communication side of one layer: per edge, fetch the input (polling), re-poison the buffer before the previous one,
@@ -192,22 +208,27 @@ __device__ __forceinline__ void layer_comm(Ctx& c, int l) {
     fetch_poll<1024>(bf.xA, 1024, c); poison<4>(bf.h, 8192, c); poison<4>(bf.h + 4096, 8192, c); LOG(0, 0);
     BAR(); BAR();
     LOG(0, 1); publish<3>(bf.q, 3072, c, 0); LOG(0, 2);
+    BAR3();
     // ---- e1 attention: q -> a
     fetch_poll<1024>(bf.q, 3072, c); poison<1>(bf.xA, 1024, c); LOG(1, 0);
     BAR(); BAR();
     LOG(1, 1); publish<1>(bf.a, 1024, c, 0); LOG(1, 2);
+    BAR3();
     // ---- e2 o_proj: a -> xB
     fetch_poll<1024>(bf.a, 1024, c); poison<3>(bf.q, 3072, c); LOG(2, 0);
     BAR(); BAR();
     LOG(2, 1); publish<1>(bf.xB, 1024, c, 0); LOG(2, 2);
+    BAR3();
     // ---- e3 gate + up: xB -> h
     fetch_poll<1024>(bf.xB, 1024, c); poison<1>(bf.a, 1024, c); LOG(3, 0);
     BAR(); BAR();
     LOG(3, 1); publish<4>(bf.h, 8192, c, 0); publish<4>(bf.h + 4096, 8192, c, 1); LOG(3, 2);
+    BAR3();
     // ---- e4 down: h[0:4096] -> xA
     fetch_poll<4096>(bf.h, 8192, c); poison<1>(bf.xB, 1024, c); LOG(4, 0);
     BAR(); BAR();
     LOG(4, 1); publish<1>(bf.xA, 1024, c, 0); LOG(4, 2);
+    BAR3();
 }
 
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 3))) void persist_kernel(Bufs bf) {
