@@ -41,6 +41,13 @@ class Info(C.Structure):
                  "wdtype", "device")] + [("weight_bytes", C.c_int64)]
 
 
+class Cond(C.Structure):
+    """t3mi_cond: the conditioning t3_inference() receives (R/t3.R:103-113)."""
+    _fields_ = [("speaker_emb", C.POINTER(C.c_float)), ("n_speaker", C.c_int32),
+                ("cond_prompt_speech_tokens", C.POINTER(C.c_int32)), ("n_cond_tokens", C.c_int32),
+                ("emotion_adv", C.c_float), ("has_emotion_adv", C.c_int32)]
+
+
 class KStat(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_int32), ("total_us", C.c_float),
                 ("bytes", C.c_double)]
@@ -60,6 +67,12 @@ SYMBOLS = {
     "t3mi_generate": (C.c_int, [_H, _FP, C.c_int, C.c_int, C.POINTER(Params), _IP, C.c_int32, _IP]),
     "t3mi_generate_batch": (C.c_int, [_H, C.c_int, C.c_int, C.POINTER(C.c_void_p), _IP, C.POINTER(Params),
                                       _IP, C.c_int32, _IP]),
+    "t3mi_prompt_shape": (C.c_int, [_H, C.POINTER(Cond), C.c_int, C.c_float, _IP, _IP, _IP]),
+    "t3mi_prepare_input_embeds": (C.c_int, [_H, C.POINTER(Cond), _IP, C.c_int, C.c_float, C.c_int32, _FP, C.c_size_t]),
+    "t3mi_generate_tokens": (C.c_int, [_H, C.POINTER(Cond), _IP, C.c_int, C.POINTER(Params), _IP, C.c_int32, _IP]),
+    "t3mi_generate_batch_tokens": (C.c_int, [_H, C.c_int, C.POINTER(Cond), C.POINTER(_IP), _IP, C.POINTER(Params),
+                                             _IP, C.c_int32, _IP]),
+    "t3mi_session_begin_tokens": (C.c_int, [_H, C.c_int, C.POINTER(Cond), C.POINTER(_IP), _IP, C.POINTER(Params)]),
     "t3mi_session_begin": (C.c_int, [_H, C.c_int, C.c_int, C.POINTER(C.c_void_p), _IP, C.POINTER(Params),
                                      C.c_int]),
     "t3mi_session_force": (C.c_int, [_H, _IP, C.c_int]),

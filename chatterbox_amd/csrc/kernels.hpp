@@ -210,6 +210,14 @@ hipError_t launch_xcc_census(int* out, hipStream_t s);
 hipError_t launch_weight_prefetch(const PfItem* plan_dev, int n_items, int* state, int base, int lookahead,
                                   int blocks, int depth, int max_polls, float* sink, hipStream_t s,
                                   long long* dbg = nullptr);
+// ---- prompt builder (prompt_kernels.hip; R/t3.R:48-90, 161-195, 278-315, 372-403) ----
+// out[r] = table[ids[r]] (+ pos[r]), r < n; ids on device, checked against the table size by the caller
+hipError_t launch_embed_rows(const float* table, const int* ids, const float* pos, float* out, int n, int d, hipStream_t s);
+// out[i] = w[i] * sc
+hipError_t launch_scale_row(const float* w, float sc, float* out, int d, hipStream_t s);
+// unmasked multi-head attention: q [Mq, H*Dh], k / v [Mk, H*Dh] -> out [Mq, H*Dh], all fp32
+hipError_t launch_mha_rows(const float* q, const float* k, const float* v, float* out, int Mq, int Mk, int H, int Dh,
+                           hipStream_t s);
 // fp32 -> bf16 (round to nearest even) on device, n elements
 hipError_t launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 

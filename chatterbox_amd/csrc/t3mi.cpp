@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "prompt.hpp"
 #include "safetensors.hpp"
 
 namespace {
@@ -127,6 +128,8 @@ struct t3mi_model {
     const float* head_b_f = nullptr;
     int64_t weight_bytes = 0;
     std::unique_ptr<Session> sess;
+    t3mi::PromptModel* prompt = nullptr;   // text_emb / cond_enc.* tensors (nullptr: decode-only checkpoint)
+    DevBuf prompt_buf;                     // prompts built on device, alive until the next build
     bool use_graph = true;
     hipStream_t pf_stream = nullptr;   // the prefetcher runs beside the decode chain
     DevBuf pf_state, pf_sink;
@@ -1005,6 +1008,15 @@ int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model*
         (void)hipStreamDestroy(m->pf_stream);
         return rc;
     }
+    {
+        std::string perr;
+        const int prc = t3mi::prompt_load(st, variant, m->d, &m->prompt, perr);
+        if (prc < 0) {
+            (void)hipStreamDestroy(m->stream);
+            (void)hipStreamDestroy(m->pf_stream);
+            return fail(prc, perr);
+        }
+    }
     if (t3k::sampler_lds_bytes(m->V) > 160 * 1024 || m->V > 16384) {
         (void)hipStreamDestroy(m->stream);
         (void)hipStreamDestroy(m->pf_stream);
@@ -1021,6 +1033,8 @@ int t3mi_close(t3mi_model* m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->pf_stream) (void)hipStreamSynchronize(m->pf_stream);
     m->sess.reset();
+    t3mi::prompt_free(m->prompt);
+    m->prompt = nullptr;
     if (m->stream) (void)hipStreamDestroy(m->stream);
     if (m->pf_stream) (void)hipStreamDestroy(m->pf_stream);
     delete m;
@@ -1506,11 +1520,8 @@ int t3mi_debug_stamp_step(t3mi_model* m, unsigned long long* out, int max_launch
 }
 #endif
 
-int t3mi_generate_batch(t3mi_model* m, int n_utt, int rpu, const float* const* embeds, const int32_t* s0,
-                        const t3mi_params* p, int32_t* out, int32_t cap, int32_t* n_out) {
-    if (!out || !n_out) return fail(T3MI_ERR_ARG, "t3mi_generate_batch: null output");
-    int rc = t3mi_session_begin(m, n_utt, rpu, embeds, s0, p, 0);
-    if (rc) return rc;
+// decode loop shared by the generate entry points: the session is open, its prefill enqueued
+static int run_generate(t3mi_model* m, int n_utt, int32_t* out, int32_t cap, int32_t* n_out) {
     Session* s = m->sess.get();
     const int max_new = s->prm.max_new_tokens;
     if (cap < max_new) {
@@ -1518,7 +1529,7 @@ int t3mi_generate_batch(t3mi_model* m, int n_utt, int rpu, const float* const* e
         return fail(T3MI_ERR_ARG, "output capacity is smaller than max_new_tokens");
     }
     std::vector<int32_t> ntok(n_utt), done(n_utt);
-    int issued = 0;
+    int issued = 0, rc = T3MI_OK;
     bool all_done = false;
     while (!all_done && issued < max_new) {
         const int chunk = std::min(32, max_new - issued);
@@ -1543,6 +1554,127 @@ int t3mi_generate_batch(t3mi_model* m, int n_utt, int rpu, const float* const* e
     }
     if (warn) g_err = "KV cache full, generation stopped (src/t3_decode.cpp:394-397)";
     return warn;
+}
+
+int t3mi_generate_batch(t3mi_model* m, int n_utt, int rpu, const float* const* embeds, const int32_t* s0,
+                        const t3mi_params* p, int32_t* out, int32_t cap, int32_t* n_out) {
+    if (!out || !n_out) return fail(T3MI_ERR_ARG, "t3mi_generate_batch: null output");
+    int rc = t3mi_session_begin(m, n_utt, rpu, embeds, s0, p, 0);
+    if (rc) return rc;
+    return run_generate(m, n_utt, out, cap, n_out);
+}
+
+// ---- prompt builder entry points -----------------------------------------------------------
+static t3mi::PromptEnv prompt_env(const t3mi_model* m, int start_token) {
+    t3mi::PromptEnv e;
+    e.variant = m->variant;
+    e.d = m->d;
+    e.vocab = m->V;
+    e.max_pos = m->variant == T3MI_VARIANT_TURBO ? 0 : m->max_pos;
+    e.speech_emb = m->emb.as<float>();
+    e.speech_pos = m->variant == T3MI_VARIANT_TURBO ? nullptr : m->pos_emb.as<float>();
+    e.start_token = start_token;
+    e.stream = m->stream;
+    return e;
+}
+static t3mi::PromptCond prompt_cond(const t3mi_cond* c) {
+    t3mi::PromptCond pc;
+    pc.speaker_emb = c->speaker_emb;
+    pc.n_speaker = c->n_speaker;
+    pc.cond_tokens = c->cond_prompt_speech_tokens;
+    pc.n_cond = c->n_cond_tokens;
+    pc.emotion = c->emotion_adv;
+    pc.has_emotion = c->has_emotion_adv;
+    return pc;
+}
+
+int t3mi_prompt_shape(t3mi_model* m, const t3mi_cond* cond, int n_text, float cfg_weight, int32_t* rows, int32_t* s0,
+                      int32_t* len_cond) {
+    if (!m || !cond || !rows || !s0 || !len_cond) return fail(T3MI_ERR_ARG, "t3mi_prompt_shape: null argument");
+    std::string err;
+    int r = 0, s = 0, lc = 0;
+    const int rc = t3mi::prompt_shape(m->prompt, prompt_env(m, 0), prompt_cond(cond), n_text, cfg_weight, &r, &s, &lc, err);
+    if (rc) return fail(rc, err);
+    *rows = r;
+    *s0 = s;
+    *len_cond = lc;
+    return T3MI_OK;
+}
+
+// builds the prompts of n_utt utterances into m->prompt_buf; ptrs[u] / s0[u] describe them
+static int build_prompts(t3mi_model* m, int n_utt, const t3mi_cond* conds, const int32_t* const* text, const int32_t* n_text,
+                         float cfg_weight, int start_token, std::vector<const float*>& ptrs, std::vector<int32_t>& s0, int* rpu) {
+    if (!m || !conds || !text || !n_text || n_utt <= 0) return fail(T3MI_ERR_ARG, "prompt: null argument");
+    HIPCHK(hipSetDevice(m->device));
+    const t3mi::PromptEnv env = prompt_env(m, start_token);
+    std::string err;
+    ptrs.assign(n_utt, nullptr);
+    s0.assign(n_utt, 0);
+    std::vector<size_t> off(n_utt);
+    size_t tot = 0;
+    int rows = 1;
+    for (int u = 0; u < n_utt; ++u) {
+        int r = 0, lc = 0;
+        const int rc = t3mi::prompt_shape(m->prompt, env, prompt_cond(&conds[u]), n_text[u], cfg_weight, &r, &s0[u], &lc, err);
+        if (rc) return fail(rc, "utterance " + std::to_string(u) + ": " + err);
+        rows = r;
+        off[u] = tot;
+        tot += (size_t)r * s0[u] * m->d;
+    }
+    // the previous call's prefill may still read the old buffer: finish it before the buffer is replaced
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->prompt_buf.bytes < tot * 4) HIPCHK(m->prompt_buf.alloc(tot * 4));
+    for (int u = 0; u < n_utt; ++u) {
+        float* dst = m->prompt_buf.as<float>() + off[u];
+        const int rc = t3mi::prompt_build(m->prompt, env, prompt_cond(&conds[u]), text[u], n_text[u], cfg_weight, dst, err);
+        if (rc) return fail(rc, "utterance " + std::to_string(u) + ": " + err);
+        ptrs[u] = dst;
+    }
+    *rpu = rows;
+    return T3MI_OK;
+}
+
+int t3mi_prepare_input_embeds(t3mi_model* m, const t3mi_cond* cond, const int32_t* text_tokens, int n_text, float cfg_weight,
+                              int32_t start_token, float* out, size_t cap_floats) {
+    if (!out || !cond) return fail(T3MI_ERR_ARG, "t3mi_prepare_input_embeds: null argument");
+    std::vector<const float*> ptrs;
+    std::vector<int32_t> s0;
+    int rpu = 1;
+    const int32_t* tt[1] = {text_tokens};
+    const int32_t nt[1] = {n_text};
+    int rc = build_prompts(m, 1, cond, tt, nt, cfg_weight, start_token, ptrs, s0, &rpu);
+    if (rc) return rc;
+    const size_t n = (size_t)rpu * s0[0] * m->d;
+    if (cap_floats < n) return fail(T3MI_ERR_ARG, "t3mi_prepare_input_embeds: output buffer too small");
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(out, ptrs[0], n * 4, hipMemcpyDeviceToHost));
+    return T3MI_OK;
+}
+
+int t3mi_session_begin_tokens(t3mi_model* m, int n_utt, const t3mi_cond* conds, const int32_t* const* text_tokens,
+                              const int32_t* n_text, const t3mi_params* p) {
+    if (!p) return fail(T3MI_ERR_ARG, "t3mi_session_begin_tokens: null params");
+    std::vector<const float*> ptrs;
+    std::vector<int32_t> s0;
+    int rpu = 1;
+    int rc = build_prompts(m, n_utt, conds, text_tokens, n_text, p->cfg_weight, p->start_token, ptrs, s0, &rpu);
+    if (rc) return rc;
+    return t3mi_session_begin(m, n_utt, rpu, ptrs.data(), s0.data(), p, 1);
+}
+
+int t3mi_generate_batch_tokens(t3mi_model* m, int n_utt, const t3mi_cond* conds, const int32_t* const* text_tokens,
+                               const int32_t* n_text, const t3mi_params* p, int32_t* out, int32_t cap, int32_t* n_out) {
+    if (!out || !n_out) return fail(T3MI_ERR_ARG, "t3mi_generate_batch_tokens: null output");
+    int rc = t3mi_session_begin_tokens(m, n_utt, conds, text_tokens, n_text, p);
+    if (rc) return rc;
+    return run_generate(m, n_utt, out, cap, n_out);
+}
+
+int t3mi_generate_tokens(t3mi_model* m, const t3mi_cond* cond, const int32_t* text_tokens, int n_text, const t3mi_params* p,
+                         int32_t* out, int32_t cap, int32_t* n_out) {
+    const int32_t* tt[1] = {text_tokens};
+    const int32_t nt[1] = {n_text};
+    return t3mi_generate_batch_tokens(m, 1, cond, tt, nt, p, out, cap, n_out);
 }
 
 int t3mi_generate(t3mi_model* m, const float* embeds, int rows, int s0, const t3mi_params* p, int32_t* out,

@@ -29,13 +29,18 @@ class T3Dims:
     max_speech_pos: int = 4100
     start_speech_token: int = 6561
     stop_speech_token: int = 6562
+    # prompt construction (R/t3.R:11-36, 263-275)
+    text_vocab: int = 704
+    max_text_pos: int = 2050
+    speaker_embed: int = 256
+    n_query: int = 32
 
 
 FULL = T3Dims()
 # reduced shape for committed goldens / fast CPU parity (head_dim stays 64)
 TINY = T3Dims(hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
               num_attention_heads=8, head_dim=64, speech_vocab=1000, max_speech_pos=600,
-              start_speech_token=990, stop_speech_token=991)
+              start_speech_token=990, stop_speech_token=991, text_vocab=300, max_text_pos=80)
 
 
 def synth_llama_weights(dims: T3Dims, seed: int = 1234, head_scale: float = 1.0) -> Dict[str, np.ndarray]:
@@ -68,6 +73,24 @@ def synth_llama_weights(dims: T3Dims, seed: int = 1234, head_scale: float = 1.0)
     w["speech_head.weight"] = lin(V, d)
     if head_scale != 1.0:
         w["speech_head.weight"] = (w["speech_head.weight"] * F32(head_scale)).astype(F32)
+    # prompt-construction tensors (keys of R/t3.R:1076-1141), drawn AFTER everything above so the decode-path
+    # tensors of a given seed keep their values.  Scales chosen so the prompt rows look like the real ones
+    # (std ~0.5, outputs/cond_enc_debug.safetensors) rather than like raw N(0, .02^2) embeddings.
+    def vec(n, mean, std):
+        return (F32(mean) + rng.standard_normal(n, dtype=F32) * F32(std)).astype(F32)
+
+    w["text_emb.weight"] = (lin(dims.text_vocab, d) * F32(20.0)).astype(F32)
+    w["text_pos_emb.emb.weight"] = (lin(dims.max_text_pos, d) * F32(5.0)).astype(F32)
+    w["cond_enc.spkr_enc.weight"] = (lin(d, dims.speaker_embed) * F32(8.0)).astype(F32)
+    w["cond_enc.spkr_enc.bias"] = vec(d, 0.0, 0.05)
+    w["cond_enc.emotion_adv_fc.weight"] = vec(d, 0.0, 0.5).reshape(d, 1)
+    qv = float(np.sqrt(3.0) * np.sqrt(2.0 / (2 * dims.n_query)))      # R/t3.R:218-221
+    w["cond_enc.perceiver.pre_attention_query"] = rng.uniform(-qv, qv, size=(1, dims.n_query, d)).astype(F32)
+    w["cond_enc.perceiver.attn.norm.weight"] = vec(d, 1.0, 0.1)
+    w["cond_enc.perceiver.attn.norm.bias"] = vec(d, 0.0, 0.05)
+    for nm in ("to_q", "to_k", "to_v", "proj_out"):
+        w[f"cond_enc.perceiver.attn.{nm}.weight"] = (lin(d, d) * F32(2.0)).astype(F32)
+        w[f"cond_enc.perceiver.attn.{nm}.bias"] = vec(d, 0.0, 0.05)
     return w
 
 
@@ -80,11 +103,13 @@ class TurboDims:
     speech_vocab: int = 6563
     start_speech_token: int = 6561
     stop_speech_token: int = 6562
+    text_vocab: int = 50276          # R/t3.R:1159
+    speaker_embed: int = 256
 
 
 TURBO_FULL = TurboDims()
 TURBO_TINY = TurboDims(hidden_size=512, n_head=8, n_layer=2, speech_vocab=900, start_speech_token=890,
-                       stop_speech_token=891)
+                       stop_speech_token=891, text_vocab=400)
 
 
 def synth_turbo_weights(dims: TurboDims, seed: int = 4321, head_scale: float = 1.0) -> Dict[str, np.ndarray]:
@@ -120,13 +145,17 @@ def synth_turbo_weights(dims: TurboDims, seed: int = 4321, head_scale: float = 1
     w["speech_emb.weight"] = lin(V, d)
     w["speech_head.weight"] = (lin(V, d) * F32(head_scale)).astype(F32)
     w["speech_head.bias"] = vec(V, 0.0, 0.02)
+    # prompt-construction tensors (R/t3.R:1508-1517), drawn after the decode-path tensors
+    w["text_emb.weight"] = (lin(dims.text_vocab, d) * F32(20.0)).astype(F32)
+    w["cond_enc.spkr_enc.weight"] = (lin(d, dims.speaker_embed) * F32(8.0)).astype(F32)
+    w["cond_enc.spkr_enc.bias"] = vec(d, 0.0, 0.05)
     return w
 
 
 def ensure_turbo_checkpoint(dims: TurboDims, seed: int = 4321, root: str | None = None, head_scale: float = 1.0) -> str:
     root = root or os.environ.get("T3MI_SYNTH_DIR", "/tmp/t3mi_synth")
     os.makedirs(root, exist_ok=True)
-    tag = f"t3turbo_L{dims.n_layer}_d{dims.hidden_size}_V{dims.speech_vocab}_s{seed}" + (
+    tag = f"t3turbo_L{dims.n_layer}_d{dims.hidden_size}_V{dims.speech_vocab}_s{seed}_p1" + (
         "" if head_scale == 1.0 else f"_h{head_scale:g}")
     path = os.path.join(root, tag + ".safetensors")
     if not os.path.exists(path):
@@ -169,7 +198,7 @@ def write_safetensors(weights: Dict[str, np.ndarray], path: str) -> str:
 def checkpoint_path(dims: T3Dims, seed: int = 1234, root: str | None = None, head_scale: float = 1.0) -> str:
     root = root or os.environ.get("T3MI_SYNTH_DIR", "/tmp/t3mi_synth")
     os.makedirs(root, exist_ok=True)
-    tag = f"t3_L{dims.num_hidden_layers}_d{dims.hidden_size}_F{dims.intermediate_size}_V{dims.speech_vocab}_s{seed}" + (
+    tag = f"t3_L{dims.num_hidden_layers}_d{dims.hidden_size}_F{dims.intermediate_size}_V{dims.speech_vocab}_s{seed}_p1" + (
         "" if head_scale == 1.0 else f"_h{head_scale:g}")
     return os.path.join(root, tag + ".safetensors")
 

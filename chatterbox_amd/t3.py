@@ -6,9 +6,14 @@ is the Python stand-in that keeps the same function names, argument names,
 defaults, return convention (0-indexed speech-token ids) and error behaviour.  The
 R glue that binds the same C entry points lives in r-package/ (INTEGRATION.md).
 
-Until the prompt builder lands, the functions take the output of
-`prepare_input_embeds` (R/t3.R:372-403) -- float32 `[rows, S0, 1024]`, rows = 2
-with CFG (cond, uncond) -- instead of `(cond, text_tokens)`.
+Two call forms, told apart by the second argument:
+
+* `t3_inference(model, cond, text_tokens, ...)` with `cond = t3_cond(...)` -- the
+  reference's own signature; the prompt (conditioning encoder, perceiver, text and
+  speech embeddings: R/t3.R:361-403) is built on the GPU by the library.
+* `t3_inference(model, embeds, ...)` with the output of `prepare_input_embeds`
+  (float32 `[rows, S0, 1024]`, rows = 2 with CFG) for callers that build the
+  prompt themselves, and for checkpoints without the `cond_enc.*` tensors.
 """
 from __future__ import annotations
 
@@ -20,7 +25,7 @@ import numpy as np
 from . import _lib
 
 __all__ = ["T3Model", "load_t3", "load_t3_turbo", "t3_inference", "t3_inference_cpp", "t3_inference_batch",
-           "t3_inference_turbo", "t3_inference_turbo_batch", "Session"]
+           "t3_inference_turbo", "t3_inference_turbo_batch", "Session", "T3Cond", "t3_cond", "prepare_input_embeds"]
 
 _DT = {"f32": _lib.W_F32, "fp32": _lib.W_F32, "float32": _lib.W_F32, "bf16": _lib.W_BF16,
        "bfloat16": _lib.W_BF16}
@@ -91,6 +96,73 @@ def _params(model: T3Model, max_new_tokens, temperature, cfg_weight, top_p, min_
     return p
 
 
+class T3Cond:
+    """t3_cond (R/t3.R:103-113): speaker embedding [256], optional conditioning speech tokens (0-indexed),
+    emotion / exaggeration scalar (None = NULL).  Keeps the numpy arrays alive for the C struct."""
+
+    def __init__(self, speaker_emb, cond_prompt_speech_tokens=None, emotion_adv: Optional[float] = 0.5):
+        self.speaker_emb = np.ascontiguousarray(speaker_emb, dtype=np.float32).reshape(-1)
+        self.cond_prompt_speech_tokens = (None if cond_prompt_speech_tokens is None else
+                                          np.ascontiguousarray(cond_prompt_speech_tokens, dtype=np.int32).reshape(-1))
+        self.emotion_adv = emotion_adv
+
+    def c_struct(self) -> _lib.Cond:
+        c = _lib.Cond()
+        c.speaker_emb = self.speaker_emb.ctypes.data_as(C.POINTER(C.c_float))
+        c.n_speaker = int(self.speaker_emb.size)
+        if self.cond_prompt_speech_tokens is not None and self.cond_prompt_speech_tokens.size:
+            c.cond_prompt_speech_tokens = self.cond_prompt_speech_tokens.ctypes.data_as(C.POINTER(C.c_int32))
+            c.n_cond_tokens = int(self.cond_prompt_speech_tokens.size)
+        c.emotion_adv = float(self.emotion_adv) if self.emotion_adv is not None else 0.0
+        c.has_emotion_adv = 0 if self.emotion_adv is None else 1
+        return c
+
+
+def t3_cond(speaker_emb, cond_prompt_speech_tokens=None, cond_prompt_speech_emb=None, emotion_adv=0.5) -> T3Cond:
+    """R/t3.R:103-113.  Pre-computed prompt-speech embeddings are not part of this path (generate() never
+    passes them: R/tts.R:296-302)."""
+    if cond_prompt_speech_emb is not None:
+        raise NotImplementedError("cond_prompt_speech_emb: pass cond_prompt_speech_tokens (as generate() does)")
+    return T3Cond(speaker_emb, cond_prompt_speech_tokens, emotion_adv)
+
+
+def _text(text_tokens) -> np.ndarray:
+    return np.ascontiguousarray(text_tokens, dtype=np.int32).reshape(-1)     # R/t3.R:469-471: 1-D or [1, T]
+
+
+def prepare_input_embeds(model: T3Model, cond: T3Cond, text_tokens, cfg_weight: float = 0.0):
+    """t3_model$prepare_input_embeds as t3_inference calls it (R/t3.R:473-494; Turbo :1593-1600): text start /
+    stop tokens added (Llama variant), BOS speech token appended, CFG row pair with the text span of row 2
+    zeroed.  Returns (embeds [rows, S0, d] float32, len_cond).  Parity hook; t3_inference builds the same
+    prompt without the round trip to the host."""
+    tt = _text(text_tokens)
+    cs = cond.c_struct()
+    rows, s0, lc = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    _lib.check(model._lib.t3mi_prompt_shape(model._h, C.byref(cs), tt.size, float(cfg_weight), C.byref(rows),
+                                            C.byref(s0), C.byref(lc)))
+    out = np.zeros((rows.value, s0.value, model.d_model), dtype=np.float32)
+    _lib.check(model._lib.t3mi_prepare_input_embeds(
+        model._h, C.byref(cs), tt.ctypes.data_as(C.POINTER(C.c_int32)), tt.size, float(cfg_weight),
+        model.start_speech_token, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+    return out, int(lc.value)
+
+
+def _generate_tokens(model: T3Model, conds: Sequence[T3Cond], texts: Sequence, p: _lib.Params, cap: int) -> List[np.ndarray]:
+    n_utt = len(conds)
+    cs = (_lib.Cond * n_utt)(*[c.c_struct() for c in conds])
+    tts = [_text(t) for t in texts]
+    ptrs = (C.POINTER(C.c_int32) * n_utt)(*[t.ctypes.data_as(C.POINTER(C.c_int32)) for t in tts])
+    nt = (C.c_int32 * n_utt)(*[t.size for t in tts])
+    out = np.zeros((n_utt, cap), dtype=np.int32)
+    n_out = (C.c_int32 * n_utt)()
+    rc = _lib.check(model._lib.t3mi_generate_batch_tokens(
+        model._h, n_utt, cs, ptrs, nt, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_int32)), cap, n_out))
+    if rc == _lib.WARN_CACHE_FULL:
+        import warnings
+        warnings.warn("KV cache full, stopping generation")       # src/t3_decode.cpp:395
+    return [out[u, : n_out[u]].astype(np.int64) for u in range(n_utt)]
+
+
 def _as_embeds(model: T3Model, embeds, cfg_weight: float) -> np.ndarray:
     e = np.ascontiguousarray(embeds, dtype=np.float32)
     if e.ndim == 2:
@@ -104,14 +176,22 @@ def _as_embeds(model: T3Model, embeds, cfg_weight: float) -> np.ndarray:
     return e
 
 
-def t3_inference(model: T3Model, embeds, max_new_tokens: int = 1000, temperature: float = 0.8,
+def t3_inference(model: T3Model, cond, text_tokens=None, max_new_tokens: int = 1000, temperature: float = 0.8,
                  cfg_weight: float = 0.5, top_p: float = 0.95, min_p: float = 0.05,
                  repetition_penalty: float = 1.2, seed: int = 0) -> np.ndarray:
     """R/t3.R:461-605.  Returns 0-indexed speech tokens, INCLUDING the stop token if it
-    was sampled (Q14).  `top_p = 0` is the deterministic (greedy) mode (Q6)."""
-    e = _as_embeds(model, embeds, cfg_weight)
+    was sampled (Q14).  `top_p = 0` is the deterministic (greedy) mode (Q6).
+    `cond` is a T3Cond (then `text_tokens` are the text ids, as in the reference) or a prompt
+    embedding array [rows, S0, d] (then `text_tokens` stays None)."""
     p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
                 _lib.SAMPLER_R, 0, seed)
+    if isinstance(cond, T3Cond):
+        if text_tokens is None:
+            raise ValueError("t3_inference(model, cond, text_tokens): text_tokens missing")
+        return _generate_tokens(model, [cond], [text_tokens], p, int(max_new_tokens))[0]
+    if text_tokens is not None:
+        raise ValueError("t3_inference(model, embeds): text_tokens only goes with a T3Cond")
+    e = _as_embeds(model, cond, cfg_weight)
     out = np.zeros(int(max_new_tokens), dtype=np.int32)
     n = C.c_int32(0)
     _lib.check(model._lib.t3mi_generate(
@@ -120,40 +200,46 @@ def t3_inference(model: T3Model, embeds, max_new_tokens: int = 1000, temperature
     return out[: n.value].astype(np.int64)
 
 
-def t3_inference_cpp(model: T3Model, embeds, max_new_tokens: int = 1000, temperature: float = 0.8,
+def t3_inference_cpp(model: T3Model, cond, text_tokens=None, max_new_tokens: int = 1000, temperature: float = 0.8,
                      cfg_weight: float = 0.5, top_p: float = 0.95, min_p: float = 0.05,
                      repetition_penalty: float = 1.2, max_cache_len: int = 350, seed: int = 0) -> np.ndarray:
     """R/t3.R:932-1050 (backend = "cpp"): 350-slot cache, cpp sampling rule (Q3/Q4),
-    result stripped at the first stop token (R/t3.R:1039-1045)."""
-    e = _as_embeds(model, embeds, cfg_weight)
+    result stripped at the first stop token (R/t3.R:1039-1045).  Same two call forms as t3_inference."""
     p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
                 _lib.SAMPLER_CPP, max_cache_len, seed)
-    out = np.zeros(int(max_new_tokens), dtype=np.int32)
-    n = C.c_int32(0)
-    rc = _lib.check(model._lib.t3mi_generate(
-        model._h, e.ctypes.data_as(C.POINTER(C.c_float)), e.shape[0], e.shape[1], C.byref(p),
-        out.ctypes.data_as(C.POINTER(C.c_int32)), out.shape[0], C.byref(n)))
-    if rc == _lib.WARN_CACHE_FULL:
-        import warnings
-        warnings.warn("KV cache full, stopping generation")       # src/t3_decode.cpp:395
-    toks = out[: n.value].astype(np.int64)
+    if isinstance(cond, T3Cond):
+        toks = _generate_tokens(model, [cond], [text_tokens], p, int(max_new_tokens))[0]
+    else:
+        e = _as_embeds(model, cond, cfg_weight)
+        out = np.zeros(int(max_new_tokens), dtype=np.int32)
+        n = C.c_int32(0)
+        rc = _lib.check(model._lib.t3mi_generate(
+            model._h, e.ctypes.data_as(C.POINTER(C.c_float)), e.shape[0], e.shape[1], C.byref(p),
+            out.ctypes.data_as(C.POINTER(C.c_int32)), out.shape[0], C.byref(n)))
+        if rc == _lib.WARN_CACHE_FULL:
+            import warnings
+            warnings.warn("KV cache full, stopping generation")       # src/t3_decode.cpp:395
+        toks = out[: n.value].astype(np.int64)
     stop = np.nonzero(toks == model.stop_speech_token)[0]
     if stop.size:
         toks = toks[: stop[0]]
     return toks
 
 
-def t3_inference_batch(model: T3Model, embeds_list: Sequence, max_new_tokens: int = 1000,
+def t3_inference_batch(model: T3Model, embeds_list: Sequence, text_tokens_list: Optional[Sequence] = None,
+                       max_new_tokens: int = 1000,
                        temperature: float = 0.8, cfg_weight: float = 0.5, top_p: float = 0.95,
                        min_p: float = 0.05, repetition_penalty: float = 1.2, seed: int = 0,
                        mask_stop: bool = False) -> List[np.ndarray]:
     """Independent utterances decoded together (the batch axis tts_chunked leaves serial,
     R/tts.R:462-474).  Same per-utterance semantics as t3_inference."""
+    p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
+                _lib.SAMPLER_R, 0, seed, mask_stop)
+    if text_tokens_list is not None:        # embeds_list holds T3Cond objects, one per utterance
+        return _generate_tokens(model, list(embeds_list), list(text_tokens_list), p, int(max_new_tokens))
     es = [_as_embeds(model, e, cfg_weight) for e in embeds_list]
     rpu = es[0].shape[0]
     n_utt = len(es)
-    p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
-                _lib.SAMPLER_R, 0, seed, mask_stop)
     ptrs = (C.c_void_p * n_utt)(*[e.ctypes.data for e in es])
     s0 = (C.c_int32 * n_utt)(*[e.shape[1] for e in es])
     out = np.zeros((n_utt, int(max_new_tokens)), dtype=np.int32)
@@ -164,39 +250,49 @@ def t3_inference_batch(model: T3Model, embeds_list: Sequence, max_new_tokens: in
     return [out[u, : n_out[u]].astype(np.int64) for u in range(n_utt)]
 
 
-def t3_inference_turbo_batch(model: T3Model, embeds_list: Sequence, max_new_tokens: int = 1000,
+def t3_inference_turbo_batch(model: T3Model, embeds_list: Sequence, text_tokens_list: Optional[Sequence] = None,
+                             max_new_tokens: int = 1000,
                              temperature: float = 0.8, top_k: int = 1000, top_p: float = 0.95,
                              repetition_penalty: float = 1.2, seed: int = 0, mask_stop: bool = False,
                              keep_stop: bool = False) -> List[np.ndarray]:
     """Independent Turbo utterances decoded together; per-utterance semantics of t3_inference_turbo."""
     if model.variant != _lib.VARIANT_TURBO:
         raise ValueError("t3_inference_turbo needs a model opened with load_t3_turbo")
-    es = [_as_embeds(model, e, 0.0) for e in embeds_list]
-    n_utt = len(es)
     p = _params(model, max_new_tokens, temperature, 0.0, top_p, 0.0, repetition_penalty,
                 _lib.SAMPLER_TURBO, 0, seed, mask_stop, top_k)
-    ptrs = (C.c_void_p * n_utt)(*[e.ctypes.data for e in es])
-    s0 = (C.c_int32 * n_utt)(*[e.shape[1] for e in es])
     cap = int(max_new_tokens) + 1            # first token from the prefill + max_new_tokens more (R/t3.R:1614-1658)
-    out = np.zeros((n_utt, cap), dtype=np.int32)
-    n_out = (C.c_int32 * n_utt)()
-    _lib.check(model._lib.t3mi_generate_batch(
-        model._h, n_utt, 1, ptrs, s0, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_int32)), cap, n_out))
+    if text_tokens_list is not None:         # embeds_list holds T3Cond objects
+        toks = _generate_tokens(model, list(embeds_list), list(text_tokens_list), p, cap)
+        n_utt = len(toks)
+    else:
+        es = [_as_embeds(model, e, 0.0) for e in embeds_list]
+        n_utt = len(es)
+        ptrs = (C.c_void_p * n_utt)(*[e.ctypes.data for e in es])
+        s0 = (C.c_int32 * n_utt)(*[e.shape[1] for e in es])
+        out = np.zeros((n_utt, cap), dtype=np.int32)
+        n_out = (C.c_int32 * n_utt)()
+        _lib.check(model._lib.t3mi_generate_batch(
+            model._h, n_utt, 1, ptrs, s0, C.byref(p), out.ctypes.data_as(C.POINTER(C.c_int32)), cap, n_out))
+        toks = [out[u, : n_out[u]].astype(np.int64) for u in range(n_utt)]
     res = []
     for u in range(n_utt):
-        t = out[u, : n_out[u]].astype(np.int64)
+        t = toks[u]
         if not keep_stop and t.size and t[-1] == model.stop_speech_token:
             t = t[:-1]                       # R/t3.R:1667-1671
         res.append(t)
     return res
 
 
-def t3_inference_turbo(model: T3Model, embeds, max_new_tokens: int = 1000, temperature: float = 0.8,
+def t3_inference_turbo(model: T3Model, cond, text_tokens=None, max_new_tokens: int = 1000, temperature: float = 0.8,
                        top_k: int = 1000, top_p: float = 0.95, repetition_penalty: float = 1.2,
                        seed: int = 0) -> np.ndarray:
-    """R/t3.R:1578-1677 after prepare_input_embeds ([1, S0, d] prompt rows): no CFG, no position term on the
-    generated tokens, top-k / top-p logit processors; a trailing stop token is removed (:1667-1671)."""
-    return t3_inference_turbo_batch(model, [embeds], max_new_tokens, temperature, top_k, top_p,
+    """R/t3.R:1578-1677: no CFG, no position term on the generated tokens, top-k / top-p logit processors; a
+    trailing stop token is removed (:1667-1671).  `cond` is a T3Cond with `text_tokens` (the reference's
+    signature) or a [1, S0, d] prompt array."""
+    if isinstance(cond, T3Cond):
+        return t3_inference_turbo_batch(model, [cond], [text_tokens], max_new_tokens, temperature, top_k, top_p,
+                                        repetition_penalty, seed)[0]
+    return t3_inference_turbo_batch(model, [cond], None, max_new_tokens, temperature, top_k, top_p,
                                     repetition_penalty, seed)[0]
 
 

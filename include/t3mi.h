@@ -111,6 +111,41 @@ int t3mi_generate_batch(t3mi_model* m, int n_utt, int rows_per_utt, const float*
                         const int32_t* s0, const t3mi_params* p, int32_t* out, int32_t cap,
                         int32_t* n_out);
 
+/* ---- prompt construction on device ------------------------------------
+ * Replaces t3_cond (R/t3.R:103-113) + prepare_conditioning / prepare_input_embeds (R/t3.R:361-403;
+ * Turbo R/t3.R:1447-1477), i.e. learned_position_embeddings (R/t3.R:48-90), t3_cond_enc (:252-316) and the
+ * perceiver resampler (:140-242), so the caller passes what t3_inference() itself receives: the
+ * conditioning and the text token ids.  Needs the checkpoint's text_emb.* / cond_enc.* tensors
+ * (R/t3.R:1076-1141); on a decode-only checkpoint these calls return T3MI_ERR_STATE. */
+typedef struct t3mi_cond {
+    const float* speaker_emb;                  /* host [n_speaker], voice-encoder embedding (256)          */
+    int32_t n_speaker;
+    const int32_t* cond_prompt_speech_tokens;  /* host [n_cond_tokens] 0-indexed ids (150 / Turbo 375), or NULL */
+    int32_t n_cond_tokens;
+    float emotion_adv;                         /* exaggeration scalar, 0.5 (R/t3.R:104); ignored by Turbo   */
+    int32_t has_emotion_adv;                   /* 0 = cond$emotion_adv is NULL (R/t3.R:304)                 */
+} t3mi_cond;
+
+/* rows (2 with cfg_weight > 0 on the Llama variant), prompt length S0 and conditioning length of the
+ * prompt t3_inference would build for n_text text tokens (start / stop text tokens NOT counted in n_text;
+ * they are added here as R/t3.R:473-477 does; Turbo adds none, R/t3.R:1590). */
+int t3mi_prompt_shape(t3mi_model* m, const t3mi_cond* cond, int n_text, float cfg_weight, int32_t* rows,
+                      int32_t* s0, int32_t* len_cond);
+/* prepare_input_embeds (R/t3.R:372-403 / :1457-1477) as t3_inference calls it (R/t3.R:473-494): writes the
+ * host array out[rows, s0, d_model] (parity hook; the generate calls below keep the prompt in HBM). */
+int t3mi_prepare_input_embeds(t3mi_model* m, const t3mi_cond* cond, const int32_t* text_tokens, int n_text,
+                              float cfg_weight, int32_t start_token, float* out, size_t cap_floats);
+/* t3_inference(model, cond, text_tokens, ...) (R/t3.R:461-605) / t3_inference_turbo (R/t3.R:1578-1677):
+ * prompt built on device, then the same loop as t3mi_generate. */
+int t3mi_generate_tokens(t3mi_model* m, const t3mi_cond* cond, const int32_t* text_tokens, int n_text,
+                         const t3mi_params* p, int32_t* out, int32_t cap, int32_t* n_out);
+int t3mi_generate_batch_tokens(t3mi_model* m, int n_utt, const t3mi_cond* conds,
+                               const int32_t* const* text_tokens, const int32_t* n_text, const t3mi_params* p,
+                               int32_t* out, int32_t cap, int32_t* n_out);
+/* t3mi_session_begin with the prompts built on device from tokens. */
+int t3mi_session_begin_tokens(t3mi_model* m, int n_utt, const t3mi_cond* conds, const int32_t* const* text_tokens,
+                              const int32_t* n_text, const t3mi_params* p);
+
 /* ---- session API: the same loop in pieces (bench timing, parity hooks) ---------------- */
 
 /* Allocate KV slabs (create_kv_cache, R/llama_traced.R:274-297), upload prompts, run the

@@ -15,6 +15,7 @@ What it restates (all citations are into /root/reference, read as text):
 * t3_inference loop + sampling tail ............. R/t3.R:461-605
 * cpp_t3_decode loop (differs in Q3/Q4) ......... src/t3_decode.cpp:301-417
 * Turbo (GPT-2) blocks + sampler ................ R/t3.R:1190-1410, 1578-1742
+* prompt construction (cond encoder, perceiver) . R/t3.R:48-90, 140-316, 361-403, 1447-1477
 
 Parity pin: the arithmetic of the reference lives in libtorch (R package
 `torch` >= 0.12, unpinned; DESCRIPTION:19).  This restatement is pinned by
@@ -571,3 +572,92 @@ def t3_inference_turbo(model: GPT2Oracle, embeds: np.ndarray, p: TurboParams, ut
         hidden, past = model.forward(e[None, None, :], past)
         last = hidden[:, -1, :]
     return tr
+
+
+# --------------------------------------------------------------------------
+# Prompt construction: conditioning encoder, perceiver resampler,
+# text / speech embeddings.  R/t3.R:48-90, 140-316, 361-403; Turbo R/t3.R:1447-1477.
+# --------------------------------------------------------------------------
+
+PERCEIVER_QUERIES = 32      # R/t3.R:274
+PERCEIVER_HEADS = 4         # R/t3.R:274
+START_TEXT_TOKEN = 255      # R/t3.R:14
+STOP_TEXT_TOKEN = 0         # R/t3.R:15
+
+
+def attention_block(w: Dict[str, np.ndarray], pfx: str, x1: np.ndarray, x2: np.ndarray,
+                    heads: int = PERCEIVER_HEADS) -> np.ndarray:
+    """AttentionBlock.forward (R/t3.R:161-195): ONE LayerNorm applied to both inputs, q from x1, k/v from x2,
+    plain softmax(q k^T / sqrt(Dh)) v, output projection, residual on the UN-normalised x1.  x1 [q, d], x2 [kv, d]."""
+    d = x1.shape[-1]
+    dh = d // heads
+    nw, nb = w[pfx + "norm.weight"], w[pfx + "norm.bias"]
+    n1 = layer_norm(x1, nw, nb, 1e-5)
+    n2 = layer_norm(x2, nw, nb, 1e-5)
+    q = linear(n1, w[pfx + "to_q.weight"], w[pfx + "to_q.bias"])
+    k = linear(n2, w[pfx + "to_k.weight"], w[pfx + "to_k.bias"])
+    v = linear(n2, w[pfx + "to_v.weight"], w[pfx + "to_v.bias"])
+    qh = q.reshape(-1, heads, dh).transpose(1, 0, 2)[None]      # [1, H, q, Dh]
+    kh = k.reshape(-1, heads, dh).transpose(1, 0, 2)[None]
+    vh = v.reshape(-1, heads, dh).transpose(1, 0, 2)[None]
+    o = sdpa(qh, kh, vh, None)[0].transpose(1, 0, 2).reshape(-1, d)
+    h = linear(o, w[pfx + "proj_out.weight"], w[pfx + "proj_out.bias"])
+    return (x1 + h).astype(F32)
+
+
+def perceiver(w: Dict[str, np.ndarray], x: np.ndarray) -> np.ndarray:
+    """Perceiver.forward (R/t3.R:227-241): the SAME attention block twice -- queries attend to the input, then
+    the result attends to itself.  x [n, d] -> [32, d]."""
+    q0 = w["cond_enc.perceiver.pre_attention_query"].reshape(-1, x.shape[-1]).astype(F32)
+    pre = attention_block(w, "cond_enc.perceiver.attn.", q0, x)
+    return attention_block(w, "cond_enc.perceiver.attn.", pre, pre)
+
+
+def cond_enc(w: Dict[str, np.ndarray], speaker_emb: np.ndarray, cond_prompt_emb: Optional[np.ndarray],
+             emotion_adv: Optional[float], use_perceiver: bool) -> np.ndarray:
+    """T3CondEnc.forward (R/t3.R:278-315): [speaker projection | (perceiver of) prompt-speech embeddings | emotion row]."""
+    spk = linear(speaker_emb.reshape(1, -1).astype(F32), w["cond_enc.spkr_enc.weight"], w["cond_enc.spkr_enc.bias"])
+    parts = [spk]
+    if cond_prompt_emb is not None:
+        parts.append(perceiver(w, cond_prompt_emb) if use_perceiver else cond_prompt_emb.astype(F32))
+    if emotion_adv is not None and "cond_enc.emotion_adv_fc.weight" in w:
+        ew = w["cond_enc.emotion_adv_fc.weight"].reshape(-1)            # Linear(1, d, bias = FALSE)
+        parts.append((ew * F32(emotion_adv)).astype(F32)[None, :])
+    return np.concatenate(parts, axis=0).astype(F32)
+
+
+def prepare_input_embeds(w: Dict[str, np.ndarray], speaker_emb: np.ndarray, cond_prompt_tokens: Optional[Sequence[int]],
+                         emotion_adv: Optional[float], text_tokens: Sequence[int], cfg_weight: float,
+                         start_speech_token: int) -> Tuple[np.ndarray, int]:
+    """t3_inference's prompt (R/t3.R:473-494) through prepare_input_embeds (R/t3.R:372-403), 0-indexed ids.
+    text_tokens: WITHOUT start/stop text tokens (they are added here, R/t3.R:473-477).
+    Returns (embeds [rows, S0, d], len_cond); rows = 2 with CFG, row 1 = text span zeroed (R/t3.R:383-386)."""
+    emb, pos = w["speech_emb.weight"], w["speech_pos_emb.emb.weight"]
+    prompt = None
+    if cond_prompt_tokens is not None:
+        ids = np.asarray(cond_prompt_tokens, dtype=np.int64)
+        prompt = (emb[ids] + pos[: ids.size]).astype(F32)                 # R/t3.R:366
+    cond = cond_enc(w, speaker_emb, prompt, emotion_adv, use_perceiver=True)
+    tt = np.concatenate([[START_TEXT_TOKEN], np.asarray(text_tokens, dtype=np.int64), [STOP_TEXT_TOKEN]])
+    text = (w["text_emb.weight"][tt] + w["text_pos_emb.emb.weight"][: tt.size]).astype(F32)   # R/t3.R:379-380
+    bos = (emb[start_speech_token] + pos[0]).astype(F32)[None, :]        # R/t3.R:389-390
+    row0 = np.concatenate([cond, text, bos], axis=0)
+    if cfg_weight > 0.0:
+        row1 = np.concatenate([cond, np.zeros_like(text), bos], axis=0)
+        return np.stack([row0, row1]).astype(F32), cond.shape[0]
+    return row0[None].astype(F32), cond.shape[0]
+
+
+def prepare_input_embeds_turbo(w: Dict[str, np.ndarray], speaker_emb: np.ndarray,
+                               cond_prompt_tokens: Optional[Sequence[int]], text_tokens: Sequence[int],
+                               start_speech_token: int) -> Tuple[np.ndarray, int]:
+    """t3_model_turbo$prepare_input_embeds (R/t3.R:1447-1477) as t3_inference_turbo calls it (R/t3.R:1593-1600):
+    no position terms, no perceiver, no emotion row, no text start/stop tokens, one row."""
+    emb = w["speech_emb.weight"]
+    prompt = None
+    if cond_prompt_tokens is not None:
+        prompt = emb[np.asarray(cond_prompt_tokens, dtype=np.int64)].astype(F32)     # R/t3.R:1452
+    cond = cond_enc(w, speaker_emb, prompt, None, use_perceiver=False)
+    text = w["text_emb.weight"][np.asarray(text_tokens, dtype=np.int64)].astype(F32)
+    bos = emb[start_speech_token].astype(F32)[None, :]
+    return np.concatenate([cond, text, bos], axis=0)[None].astype(F32), cond.shape[0]
