@@ -19,12 +19,34 @@ t3mi_model <- function (path, device = 0L, dtype = c("f32", "bf16"), variant = c
     .t3mi[[key]]
 }
 
+# t3_cond (R/t3.R:103-113) as the plain vectors the native prompt builder takes
+.t3mi_cond <- function (cond)
+{
+    emo <- cond$emotion_adv
+    if (inherits(emo, "torch_tensor")) emo <- as.numeric(emo$cpu())
+    list(speaker_emb = as.numeric(cond$speaker_emb$cpu()),
+         tokens = if (is.null(cond$cond_prompt_speech_tokens)) NULL
+                  else as.integer(cond$cond_prompt_speech_tokens$cpu()),
+         emotion_adv = if (is.null(emo)) NULL else as.numeric(emo)[1])
+}
+
 .t3mi_decode <- function (model, cond, text_tokens, cfg, native, sampler, max_cache_len = 0L)
 {
     config <- model$config
     device <- model$text_emb$weight$device
+    cfg$stop_token <- as.integer(config$stop_speech_token)
+    cfg$start_token <- as.integer(config$start_speech_token)
+    cfg$sampler <- as.integer(sampler)
+    cfg$max_cache_len <- as.integer(max_cache_len)
+    if (is.null(cond$cond_prompt_speech_emb)) {
+        # the whole of t3_inference natively: conditioning encoder, perceiver, embeddings, prefill, decode
+        # (prepare_input_embeds R/t3.R:372-403 runs on the GPU; the ids stay 0-indexed as tokenized)
+        ids <- .Call("t3mi_r_generate_tokens", native, list(.t3mi_cond(cond)),
+                     list(as.integer(text_tokens$cpu())), cfg, PACKAGE = "chatterbox")[[1]]
+        return(list(ids = ids, device = device, stop = config$stop_speech_token))
+    }
+    # pre-computed prompt-speech embeddings (not produced by generate()): prompt built in R torch
     if (text_tokens$dim() == 1) text_tokens <- text_tokens$unsqueeze(1)
-    # prompt construction stays in R torch until SURVEY f1 lands (R/t3.R:474-495)
     text_tokens <- torch::nnf_pad(text_tokens, c(1, 0), value = config$start_text_token)
     text_tokens <- torch::nnf_pad(text_tokens, c(0, 1), value = config$stop_text_token)
     bos <- torch::torch_tensor(matrix(config$start_speech_token, nrow = 1), device = device,
@@ -35,10 +57,6 @@ t3mi_model <- function (path, device = 0L, dtype = c("f32", "bf16"), variant = c
     }
     embeds <- torch::with_no_grad(model$prepare_input_embeds(cond, text_tokens, bos, cfg$cfg_weight)$embeds)
     e <- as.array(embeds$to(device = "cpu", dtype = torch::torch_float32()))   # [rows, S0, d], column-major
-    cfg$stop_token <- as.integer(config$stop_speech_token)
-    cfg$start_token <- as.integer(config$start_speech_token)
-    cfg$sampler <- as.integer(sampler)
-    cfg$max_cache_len <- as.integer(max_cache_len)
     ids <- .Call("t3mi_r_generate", native, e, as.integer(dim(e)), cfg, PACKAGE = "chatterbox")
     list(ids = ids, device = device, stop = config$stop_speech_token)
 }
@@ -87,18 +105,14 @@ t3_inference_turbo <- function (model, cond, text_tokens, max_new_tokens = 1000,
 {
     config <- model$config
     device <- model$speech_emb$weight$device
-    if (text_tokens$dim() == 1L) text_tokens <- text_tokens$unsqueeze(1L)
-    speech_start <- torch::torch_tensor(matrix(config$start_speech_token, nrow = 1L), device = device,
-                                        dtype = torch::torch_long())
-    # prompt construction stays in R torch until SURVEY f1 lands (R/t3.R:1599)
-    embeds <- torch::with_no_grad(model$prepare_input_embeds(cond, text_tokens, speech_start)$embeds)
-    e <- as.array(embeds$to(device = "cpu", dtype = torch::torch_float32()))   # [1, S0, d]
     cfg <- list(max_tokens = as.integer(max_new_tokens), temperature = as.double(temperature),
                 cfg_weight = 0, top_k = as.integer(top_k), top_p = as.double(top_p), min_p = 0,
                 rep_penalty = as.double(repetition_penalty), sampler = 2L,
                 start_token = as.integer(config$start_speech_token),
                 stop_token = as.integer(config$stop_speech_token))
-    ids <- .Call("t3mi_r_generate", native, e, as.integer(dim(e)), cfg, PACKAGE = "chatterbox")
+    # prompt (speaker row + prompt-token embeddings + text embeddings + BOS, R/t3.R:1447-1477) built on the GPU
+    ids <- .Call("t3mi_r_generate_tokens", native, list(.t3mi_cond(cond)), list(as.integer(text_tokens$cpu())),
+                 cfg, PACKAGE = "chatterbox")[[1]]
     n <- length(ids)
     if (n > 0L && ids[n] == config$stop_speech_token) {
         message("EOS at step ", n)
@@ -106,4 +120,23 @@ t3_inference_turbo <- function (model, cond, text_tokens, max_new_tokens = 1000,
     }
     if (length(ids) > 0L) torch::torch_tensor(ids, dtype = torch::torch_long(), device = device)
     else torch::torch_tensor(integer(0), device = device)
+}
+
+#' Many utterances at once (the batch axis tts_chunked leaves serial, R/tts.R:462-474): `conds` and
+#' `text_tokens_list` are lists of the per-sentence arguments of t3_inference; returns a list of token tensors.
+t3_inference_batch <- function (model, conds, text_tokens_list, max_new_tokens = 1000,
+                                temperature = 0.8, cfg_weight = 0.5, top_p = 0.95,
+                                min_p = 0.05, repetition_penalty = 1.2,
+                                native = t3mi_model(attr(model, "t3_path")))
+{
+    config <- model$config
+    device <- model$text_emb$weight$device
+    cfg <- list(max_tokens = as.integer(max_new_tokens), temperature = as.double(temperature),
+                cfg_weight = as.double(cfg_weight), top_p = as.double(top_p), min_p = as.double(min_p),
+                rep_penalty = as.double(repetition_penalty), sampler = 0L,
+                start_token = as.integer(config$start_speech_token),
+                stop_token = as.integer(config$stop_speech_token))
+    ids <- .Call("t3mi_r_generate_tokens", native, lapply(conds, .t3mi_cond),
+                 lapply(text_tokens_list, function (t) as.integer(t$cpu())), cfg, PACKAGE = "chatterbox")
+    lapply(ids, function (v) torch::torch_tensor(v, dtype = torch::torch_long(), device = device))
 }

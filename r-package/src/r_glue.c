@@ -2,8 +2,9 @@
  *     SEXP cpp_t3_decode(SEXP x 11)            /root/reference src/t3_decode.cpp:207-219
  *     registered in R_init_chatterbox           /root/reference src/init.c:5-15
  * The reference passes R-torch external pointers (src/t3_decode.cpp:26-32); here the model is
- * an external pointer to a t3mi handle that owns its weights in HBM, the prompt is a plain
- * numeric array, and the decode parameters are the SAME named list the reference builds at
+ * an external pointer to a t3mi handle that owns its weights in HBM, the prompt is either the
+ * conditioning + text token ids t3_inference() receives (built on the GPU, t3mi_generate_tokens) or
+ * a plain numeric [rows, S0, d] array, and the decode parameters are the SAME named list the reference builds at
  * R/t3.R:1022-1034 (read by name, like src/t3_decode.cpp:43-64, 221-231).
  *
  * Not compiled in the build container (no R headers there); compiled by the package's
@@ -162,11 +163,103 @@ SEXP t3mi_r_generate_batch(SEXP model, SEXP embeds_list, SEXP dims, SEXP cfg) {
     return res;
 }
 
+/* one utterance's conditioning from plain R vectors: list(speaker_emb = numeric, tokens = integer or NULL,
+ * emotion_adv = numeric(1) or NULL) -- the fields of t3_cond (R/t3.R:103-113) after as.numeric / as.integer.
+ * The float / int32 copies live in `hold` (caller frees). */
+typedef struct { float* spk; int32_t* tok; int32_t* text; } cond_hold;
+
+static int fill_cond(SEXP cond, SEXP text, t3mi_cond* c, cond_hold* h, int32_t* n_text) {
+    memset(c, 0, sizeof(*c));
+    memset(h, 0, sizeof(*h));
+    SEXP names = Rf_getAttrib(cond, R_NamesSymbol);
+    SEXP spk = R_NilValue, tok = R_NilValue, emo = R_NilValue;
+    if (TYPEOF(cond) != VECSXP || names == R_NilValue) return 0;
+    for (R_xlen_t i = 0; i < Rf_xlength(cond); i++) {
+        const char* nm = CHAR(STRING_ELT(names, i));
+        if (strcmp(nm, "speaker_emb") == 0) spk = VECTOR_ELT(cond, i);
+        else if (strcmp(nm, "tokens") == 0) tok = VECTOR_ELT(cond, i);
+        else if (strcmp(nm, "emotion_adv") == 0) emo = VECTOR_ELT(cond, i);
+    }
+    if (!Rf_isReal(spk) || !Rf_isInteger(text) || (tok != R_NilValue && !Rf_isInteger(tok))) return 0;
+    const R_xlen_t ns = Rf_xlength(spk), nt = tok == R_NilValue ? 0 : Rf_xlength(tok), nx = Rf_xlength(text);
+    h->spk = (float*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(float));
+    h->tok = (int32_t*)malloc((size_t)(nt > 0 ? nt : 1) * sizeof(int32_t));
+    h->text = (int32_t*)malloc((size_t)(nx > 0 ? nx : 1) * sizeof(int32_t));
+    if (!h->spk || !h->tok || !h->text) return 0;
+    for (R_xlen_t i = 0; i < ns; i++) h->spk[i] = (float)REAL(spk)[i];
+    for (R_xlen_t i = 0; i < nt; i++) h->tok[i] = (int32_t)INTEGER(tok)[i];
+    for (R_xlen_t i = 0; i < nx; i++) h->text[i] = (int32_t)INTEGER(text)[i];
+    c->speaker_emb = h->spk;
+    c->n_speaker = (int32_t)ns;
+    c->cond_prompt_speech_tokens = nt > 0 ? h->tok : NULL;
+    c->n_cond_tokens = (int32_t)nt;
+    c->has_emotion_adv = emo != R_NilValue && Rf_length(emo) > 0;
+    c->emotion_adv = c->has_emotion_adv ? (float)Rf_asReal(emo) : 0.0f;
+    *n_text = (int32_t)nx;
+    return 1;
+}
+
+static void free_hold(cond_hold* h, int n) {
+    if (!h) return;
+    for (int u = 0; u < n; u++) { free(h[u].spk); free(h[u].tok); free(h[u].text); }
+    free(h);
+}
+
+/* .Call("t3mi_r_generate_tokens", model, list_of_cond, list_of_text_tokens, config) -> list of integer vectors.
+ * The whole of t3_inference(model, cond, text_tokens, ...) (R/t3.R:461-605) for one or many utterances: prompt
+ * built on the GPU (prepare_input_embeds, R/t3.R:372-403), prefill, decode loop.  Text tokens WITHOUT the
+ * start / stop text tokens (added by the library as R/t3.R:473-477 does), 0-indexed as the tokenizer gives them. */
+SEXP t3mi_r_generate_tokens(SEXP model, SEXP conds, SEXP texts, SEXP cfg) {
+    t3mi_model* m = get_model(model);
+    const int n_utt = Rf_length(conds);
+    if (n_utt <= 0 || TYPEOF(conds) != VECSXP || TYPEOF(texts) != VECSXP || Rf_length(texts) != n_utt)
+        Rf_error("t3mi: conds and text_tokens must be lists of the same positive length");
+    t3mi_params p;
+    fill_params(cfg, &p);
+    const int cap = (p.max_new_tokens > 0 ? p.max_new_tokens : 1) + 1;   /* Turbo returns up to max_tokens + 1 ids */
+    t3mi_cond* c = (t3mi_cond*)calloc((size_t)n_utt, sizeof(t3mi_cond));
+    cond_hold* h = (cond_hold*)calloc((size_t)n_utt, sizeof(cond_hold));
+    const int32_t** tp = (const int32_t**)calloc((size_t)n_utt, sizeof(int32_t*));
+    int32_t* nt = (int32_t*)calloc((size_t)n_utt, sizeof(int32_t));
+    int32_t* out = (int32_t*)malloc((size_t)n_utt * cap * sizeof(int32_t));
+    int32_t* n_out = (int32_t*)calloc((size_t)n_utt, sizeof(int32_t));
+    int rc = (c && h && tp && nt && out && n_out) ? T3MI_OK : T3MI_ERR_ARG;
+    for (int u = 0; u < n_utt && rc == T3MI_OK; u++) {
+        if (!fill_cond(VECTOR_ELT(conds, u), VECTOR_ELT(texts, u), &c[u], &h[u], &nt[u])) rc = T3MI_ERR_ARG;
+        tp[u] = h[u].text;
+    }
+    const int bad_args = rc != T3MI_OK;
+    if (rc == T3MI_OK) rc = t3mi_generate_batch_tokens(m, n_utt, c, tp, nt, &p, out, cap, n_out);
+    free(c);
+    free_hold(h, n_utt);
+    free((void*)tp);
+    free(nt);
+    if (rc < 0) { /* free C state first, then longjmp (SURVEY 8b "Errors") */
+        free(out);
+        free(n_out);
+        Rf_error("t3mi_generate_tokens: %s", bad_args ? "cond must be list(speaker_emb = numeric, tokens = integer, "
+                 "emotion_adv = numeric), text_tokens integer" : t3mi_last_error());
+    }
+    SEXP res = PROTECT(Rf_allocVector(VECSXP, n_utt));
+    for (int u = 0; u < n_utt; u++) {
+        SEXP v = PROTECT(Rf_allocVector(INTSXP, n_out[u]));
+        for (int i = 0; i < n_out[u]; i++) INTEGER(v)[i] = (int)out[(size_t)u * cap + i];
+        SET_VECTOR_ELT(res, u, v);
+        UNPROTECT(1);
+    }
+    free(out);
+    free(n_out);
+    if (rc == T3MI_WARN_CACHE_FULL) Rf_warning("KV cache full, stopping generation"); /* src/t3_decode.cpp:395 */
+    UNPROTECT(1);
+    return res;
+}
+
 static const R_CallMethodDef call_methods[] = {
     {"t3mi_r_open", (DL_FUNC)&t3mi_r_open, 4},
     {"t3mi_r_close", (DL_FUNC)&t3mi_r_close, 1},
     {"t3mi_r_generate", (DL_FUNC)&t3mi_r_generate, 4},
     {"t3mi_r_generate_batch", (DL_FUNC)&t3mi_r_generate_batch, 4},
+    {"t3mi_r_generate_tokens", (DL_FUNC)&t3mi_r_generate_tokens, 4},
     {NULL, NULL, 0}};
 
 /* same registration pattern as the reference's src/init.c:12-15 */
