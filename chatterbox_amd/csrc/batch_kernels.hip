@@ -364,14 +364,19 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
 // LDS in a fixed order.
 template <typename KVT> struct KvLoad;
 template <> struct KvLoad<float> {
-    __device__ static __forceinline__ void load8(const float* p, float (&o)[8]) {
-        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    struct Raw { float4 a, b; };
+    __device__ static __forceinline__ Raw fetch(const float* p) {
+        return Raw{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)};
+    }
+    __device__ static __forceinline__ void unpack(const Raw& r, float (&o)[8]) {
+        o[0] = r.a.x; o[1] = r.a.y; o[2] = r.a.z; o[3] = r.a.w; o[4] = r.b.x; o[5] = r.b.y; o[6] = r.b.z; o[7] = r.b.w;
     }
 };
 template <> struct KvLoad<uint16_t> {
-    __device__ static __forceinline__ void load8(const uint16_t* p, float (&o)[8]) {
-        const uint4 u = *reinterpret_cast<const uint4*>(p);
+    struct Raw { uint4 u; };
+    __device__ static __forceinline__ Raw fetch(const uint16_t* p) { return Raw{*reinterpret_cast<const uint4*>(p)}; }
+    __device__ static __forceinline__ void unpack(const Raw& r, float (&o)[8]) {
+        const uint4 u = r.u;
         o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xFFFF0000u);
         o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xFFFF0000u);
         o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xFFFF0000u);
@@ -408,35 +413,59 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsArgs a) {
     float m_run = -INFINITY, l_run = 0.f, acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    // keys of this stream: wave*8 + kg, then every 32nd
-    for (int k0 = wave * 8 + kg; k0 < L + 31; k0 += 64) {
-        // two keys per trip (k0 and k0 + 32) so that four cache loads are in flight per lane
-        const int ka = k0, kb = k0 + 32;
-        const bool oka = ka < L, okb = kb < L;
-        float kva[8], kvb[8], vva[8], vvb[8];
-        KvLoad<KVT>::load8(kp + (size_t)(oka ? ka : 0) * kHeadDim, kva);
-        KvLoad<KVT>::load8(kp + (size_t)(okb ? kb : 0) * kHeadDim, kvb);
-        KvLoad<KVT>::load8(vp + (size_t)(oka ? ka : 0) * kHeadDim, vva);
-        KvLoad<KVT>::load8(vp + (size_t)(okb ? kb : 0) * kHeadDim, vvb);
-        float sa = 0.f, sb = 0.f;
+    // keys of this stream: wave*8 + kg, then every 32nd; a trip takes two of them (k and k + 32: four cache loads per
+    // lane).  The loads run kAhead trips ahead of the arithmetic in a register ring (the cache comes from HBM:
+    // a trip that waits for its own loads exposes one full memory latency per 64 keys of the block).
+    constexpr int kAhead = 3;
+    using Raw = typename KvLoad<KVT>::Raw;
+    Raw rka[kAhead], rkb[kAhead], rva[kAhead], rvb[kAhead];
+    const int kfirst = wave * 8 + kg;
+    const int trips = (L + 31 - kfirst + 63) / 64;   // trips of this stream (same bound as `k0 < L + 31`)
+    auto issue = [&](int t, int slot) {
+        const int ka = kfirst + t * 64, kb = ka + 32;
+        const size_t oa = (size_t)(ka < L ? ka : 0) * kHeadDim, ob = (size_t)(kb < L ? kb : 0) * kHeadDim;
+        rka[slot] = KvLoad<KVT>::fetch(kp + oa);
+        rkb[slot] = KvLoad<KVT>::fetch(kp + ob);
+        rva[slot] = KvLoad<KVT>::fetch(vp + oa);
+        rvb[slot] = KvLoad<KVT>::fetch(vp + ob);
+    };
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sa = fmaf(qv[e], kva[e], sa);
-            sb = fmaf(qv[e], kvb[e], sb);
-        }
-        // sum over the 8 lanes of the key (lanes kg*8 .. kg*8+7)
-        sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
-        sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
-        sa += __shfl_xor(sa, 4, 64); sb += __shfl_xor(sb, 4, 64);
-        sa = oka ? sa * 0.125f : -INFINITY;
-        sb = okb ? sb * 0.125f : -INFINITY;
-        const float mn = fmaxf(m_run, fmaxf(sa, sb));
-        if (mn > -INFINITY) {
-            const float sc = expf(m_run - mn), pa = expf(sa - mn), pb = expf(sb - mn);
-            l_run = fmaf(l_run, sc, pa + pb);
+    for (int u = 0; u < kAhead; ++u)
+        if (u < trips) issue(u, u);
+    for (int t0 = 0; t0 < trips; t0 += kAhead) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pb, vvb[e], fmaf(pa, vva[e], acc[e] * sc));
-            m_run = mn;
+        for (int u = 0; u < kAhead; ++u) {
+            const int t = t0 + u;
+            if (t < trips) {
+                const int ka = kfirst + t * 64, kb = ka + 32;
+                const bool oka = ka < L, okb = kb < L;
+                float kva[8], kvb[8], vva[8], vvb[8];
+                KvLoad<KVT>::unpack(rka[u], kva);
+                KvLoad<KVT>::unpack(rkb[u], kvb);
+                KvLoad<KVT>::unpack(rva[u], vva);
+                KvLoad<KVT>::unpack(rvb[u], vvb);
+                if (t + kAhead < trips) issue(t + kAhead, u);
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sa = fmaf(qv[e], kva[e], sa);
+                    sb = fmaf(qv[e], kvb[e], sb);
+                }
+                // sum over the 8 lanes of the key (lanes kg*8 .. kg*8+7)
+                sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
+                sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
+                sa += __shfl_xor(sa, 4, 64); sb += __shfl_xor(sb, 4, 64);
+                sa = oka ? sa * 0.125f : -INFINITY;
+                sb = okb ? sb * 0.125f : -INFINITY;
+                const float mn = fmaxf(m_run, fmaxf(sa, sb));
+                if (mn > -INFINITY) {
+                    const float sc = expf(m_run - mn), pa = expf(sa - mn), pb = expf(sb - mn);
+                    l_run = fmaf(l_run, sc, pa + pb);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(pb, vvb[e], fmaf(pa, vva[e], acc[e] * sc));
+                    m_run = mn;
+                }
+            }
         }
     }
     // merge the 32 streams (4 waves x 8 key groups): stream id = wave*8 + kg
@@ -473,15 +502,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* const* __
 // y[M,N] = A[M,K] * W[N,K]^T with bf16 operands, fp32 accumulate, for up to 128 rows per block.
 //
 // Block = 8 waves = 128 rows x 32 output features x one K range.  Wave w owns rows 16w..16w+15 and both 16-feature
-// sub-tiles, so it holds 2 accumulator tiles and reads its activation rows straight from global memory (L2), every
-// element exactly once per block and in whole 256-byte runs (lane (n, g) takes the 64 bytes k = g*32..g*32+31 of
-// its row per 128-k step: MFMA j of the step uses k = g*32 + 8j..8j+7 from both operands, a fixed permutation of
-// the dot product's terms).  The weight tile of a step (32 rows x 256 B, whole lines) goes global -> registers ->
-// LDS once per block and is shared by the 8 waves; a two-deep register ring keeps two steps of activations and one
-// of weights in flight.  The two sub-tiles hold PARTNER features of the fused epilogues (gate / up, rotate_half
-// i / i+32), so SwiGLU and RoPE finish in registers.  Compared with the first-generation kernel (16 features x K
-// split over the waves, every block re-reading all activation rows in 64-byte pieces) the L2 traffic for the
-// activations drops 2-4x and every request is a whole line: gate_up at 128 rows 31 us -> see DESIGN.md.
+// sub-tiles, so it holds 2 accumulator tiles.  A 128-k step's tile (128 activation rows + 32 weight rows, 256 B
+// each, whole lines: 16 consecutive lanes fetch one row's run) goes global -> registers -> LDS once per block and
+// is shared by the 8 waves; register rings keep kDA steps of activations (from L2) and kDW steps of weights (from
+// HBM: for K <= 1024 the block's whole weight slice) in flight.  Lane (n, g) reads k = g*32..g*32+31 of its row
+// from LDS per step: MFMA j of the step uses k = g*32 + 8j..8j+7 from both operands, a fixed permutation of the
+// dot product's terms.  The two sub-tiles hold PARTNER features of the fused epilogues (gate / up, rotate_half
+// i / i+32), so SwiGLU and RoPE finish in registers.  Measured at 128 rows (profiles/r01_micro_gemm_m128.txt):
+// first tile in LDS after 1.4-3.8 us, ~0.65 us per step (LDS-bandwidth bound: 40 KB written + 96 KB read).
 // Residual GEMMs with few feature tiles (N = 1024) split K over blockIdx.z into fp32 partial slabs that
 // fold_partials_kernel sums in a fixed order (deterministic, no atomics).
 template <int EPI>
