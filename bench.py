@@ -54,12 +54,12 @@ def prompt_embeds(s0: int, d: int, seed: int) -> np.ndarray:
     return synth.synth_embeds(2, s0, d, 1000 + seed)
 
 
-def step_bytes(info, rows: int, L: float, b_w: int) -> float:
+def step_bytes(info, rows: int, L: float, b_w: int, b_kv: int = 4) -> float:
     """Algorithmic bytes of one decode step, SURVEY §8d:
-    B_step = P*b_w + R*n_layers*2*d*(L+1)*b_kv + R*V*4 ;  b_kv = 4 (fp32 cache)."""
+    B_step = P*b_w + R*n_layers*2*d*(L+1)*b_kv + R*V*4 ;  b_kv = 4 (fp32 cache) or 2 (bf16 cache)."""
     d, F, V, nl = info.d_model, info.d_ff, info.vocab, info.n_layers
     P = nl * (4 * d * d + 3 * d * F + 2 * d) + d + V * d
-    return P * b_w + rows * nl * 2 * d * (L + 1) * 4 + rows * V * 4
+    return P * b_w + rows * nl * 2 * d * (L + 1) * b_kv + rows * V * 4
 
 
 def cpu_baseline(n_steps: int, s0: int, emb: np.ndarray):
@@ -136,7 +136,11 @@ def main():
     rows = 2 * U
     K, W = args.steps, args.warmup
     embs = [prompt_embeds(args.s0, dims.hidden_size, rank * U + u) for u in range(U)]
+    torch.cuda.synchronize()
+    tp0 = time.perf_counter()
     sess = cb.Session(model, embs, max_new_tokens=K + W + 8, top_p=0.0, mask_stop=True)
+    sess.sync()
+    prefill_ms = (time.perf_counter() - tp0) * 1e3   # prompt upload + cache allocation + prefill, host wall clock
 
     if W > 0:
         sess.decode(W)
@@ -157,7 +161,9 @@ def main():
 
     b_w = 4 if args.dtype == "f32" else 2
     L_avg = args.s0 + W + (K - 1) / 2.0          # cache length before the step, averaged over the timed steps
-    bstep = step_bytes(info, rows, L_avg, b_w)
+    # the library keeps a bf16 KV cache when bf16 weights meet more than 4 activation rows
+    kv_bf16 = args.dtype == "bf16" and rows > 4 and os.environ.get("T3MI_KV", "")[:1] != "f"
+    bstep = step_bytes(info, rows, L_avg, b_w, 2 if kv_bf16 else 4)
     step_us = ev_ms * 1e3 / K
     achieved = bstep / (step_us * 1e-6) / 1e9
     roof = {"bound": "hbm", "kernel": "decode_step (1 sampler + 30x[qkv_rope_kv, attn_decode, o_proj_resid, "
@@ -211,12 +217,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16-weights/f32-accumulate",
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: {U} utterance(s)/GPU x CFG cond/uncond pair ({rows} rows), greedy top_p=0, "
-                                   f"S0={args.s0}, Llama-520M (30x d1024/F4096, V8194) synthetic weights in the reference "
-                                   f"safetensors layout, {args.dtype} weights, fp32 KV cache",
+            "config": {"workload": f"{'configs[1]' if U == 1 else 'configs[2]-shaped'}: {U} utterance(s)/GPU x CFG cond/uncond pair "
+                                   f"({rows} rows), greedy top_p=0, S0={args.s0}, Llama-520M (30x d1024/F4096, V8194) synthetic "
+                                   f"weights in the reference safetensors layout, {args.dtype} weights, "
+                                   f"{'bf16' if kv_bf16 else 'fp32'} KV cache",
                        "utterances_per_gpu": U, "rows_per_gpu": rows, "s0": args.s0,
                        "parallelism": f"utterance-sharded x{n_gpus} (no collectives)"},
             "hip_event_ms_per_step": round(ev_ms / K, 5),
+            "prefill_ms": round(prefill_ms, 3),   # rank 0: session set-up + prefill of its utterances (not in `value`)
             "roofline": roof,
             "cpu_baseline": cpu,
         }
