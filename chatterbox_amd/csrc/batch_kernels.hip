@@ -722,12 +722,16 @@ hipError_t launch_gemm_rows_bf16(const GemmArgs& a, hipStream_t s) {
             ks *= 2;
     }
     constexpr int lds = 2 * 160 * (128 + 8) * 2;   // 87,040 B: two step tiles
-    static bool attr_done = false;   // per EPI instantiation
-    if (!attr_done) {
+    // the attribute belongs to the (kernel, device) pair: one flag per EPI instantiation and device
+    static bool attr_done[64] = {};
+    int dev = 0;
+    hipError_t ed = hipGetDevice(&dev);
+    if (ed != hipSuccess) return ed;
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
         hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_bf16_kernel<EPI>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e0 != hipSuccess) return e0;
-        attr_done = true;
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     hipLaunchKernelGGL(gemm_rows_bf16_kernel<EPI>, dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     hipError_t e = hipGetLastError();
