@@ -43,9 +43,14 @@ struct PromptModel {
     const float *text_emb = nullptr, *text_pos = nullptr, *spk_w = nullptr, *spk_b = nullptr, *emo_w = nullptr,
                 *query = nullptr, *ln_w = nullptr, *ln_b = nullptr, *wq = nullptr, *bq = nullptr, *wk = nullptr,
                 *bk = nullptr, *wv = nullptr, *bv = nullptr, *wo = nullptr, *bo = nullptr;
-    Buf scratch, ids;
-    std::vector<int32_t> host_ids;
-    std::vector<float> host_spk;
+    Buf scratch;
+    // per-batch staging of the host inputs: every utterance gets its own slice of the device arenas and its own
+    // host copy, so an asynchronous upload never races the next utterance's (the copies may still be in flight when
+    // prompt_build returns); both are recycled by prompt_batch_begin, which the caller runs on a drained stream
+    Buf ids_arena, spk_arena;
+    size_t ids_off = 0, spk_off = 0;
+    std::vector<std::vector<int32_t>> hold_ids;
+    std::vector<std::vector<float>> hold_spk;
 };
 
 namespace {
@@ -152,6 +157,16 @@ int prompt_load(const SafeTensorsFile& st, int variant, int d, PromptModel** out
     return 0;
 }
 
+int prompt_batch_begin(PromptModel* pm, size_t total_ids, int n_utt, std::string& err) {
+    if (!pm) return T3MI_OK;   // prompt_shape reports the missing tensors
+    PHIP(pm->ids_arena.reserve((total_ids + 16) * 4));
+    PHIP(pm->spk_arena.reserve(((size_t)n_utt * pm->spk_dim + 16) * 4));
+    pm->ids_off = pm->spk_off = 0;
+    pm->hold_ids.clear();
+    pm->hold_spk.clear();
+    return T3MI_OK;
+}
+
 int prompt_shape(const PromptModel* pm, const PromptEnv& env, const PromptCond& c, int n_text, float cfg_weight, int* rows,
                  int* s0, int* len_cond, std::string& err) {
     if (!pm) {
@@ -239,26 +254,31 @@ int prompt_build(PromptModel* pm, const PromptEnv& env, const PromptCond& c, con
         return T3MI_ERR_ARG;
     }
     // ids on device: [cond tokens | text tokens (with start / stop) | start speech token]
-    std::vector<int32_t>& ids = pm->host_ids;
-    ids.clear();
+    pm->hold_ids.emplace_back();
+    std::vector<int32_t>& ids = pm->hold_ids.back();
     ids.insert(ids.end(), c.cond_tokens, c.cond_tokens + n_cond);
     if (llama) ids.push_back(kStartText);
     ids.insert(ids.end(), text_tokens, text_tokens + n_text);
     if (llama) ids.push_back(kStopText);
     ids.push_back(env.start_token);
-    PHIP(pm->ids.reserve(ids.size() * 4));
-    PHIP(hipMemcpyAsync(pm->ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
-    const int* id_cond = pm->ids.as<int>();
+    if ((pm->ids_off + ids.size()) * 4 > pm->ids_arena.bytes || (pm->spk_off + pm->spk_dim) * 4 > pm->spk_arena.bytes) {
+        err = "prompt: staging arenas too small (prompt_batch_begin not called for this batch)";
+        return T3MI_ERR_STATE;
+    }
+    int* ids_dev = pm->ids_arena.as<int>() + pm->ids_off;
+    pm->ids_off += ids.size();
+    PHIP(hipMemcpyAsync(ids_dev, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
+    const int* id_cond = ids_dev;
     const int* id_text = id_cond + n_cond;
     const int* id_bos = id_text + n_tt;
 
-    // scratch rows: speaker vector | E, N2, K, V [mk] | N1, Q, A, P [nq]
+    // scratch rows (reused by every utterance, in stream order): E, N2, K, V [mk] | N1, Q, A, P [nq]
     const int nq = pm->perceiver ? pm->n_query : 0;
     const int mk = std::max(n_cond, nq);
-    const size_t spk_slot = ((size_t)pm->spk_dim + 63) / 64 * 64;
-    PHIP(pm->scratch.reserve((spk_slot + (size_t)(4 * mk + 4 * nq) * d) * 4));
-    float* spk = pm->scratch.as<float>();
-    float* E = spk + spk_slot;
+    PHIP(pm->scratch.reserve(((size_t)(4 * mk + 4 * nq) * d + 16) * 4));
+    float* spk = pm->spk_arena.as<float>() + pm->spk_off;
+    pm->spk_off += pm->spk_dim;
+    float* E = pm->scratch.as<float>();
     float* N2 = E + (size_t)mk * d;
     float* K = N2 + (size_t)mk * d;
     float* V = K + (size_t)mk * d;
@@ -266,8 +286,8 @@ int prompt_build(PromptModel* pm, const PromptEnv& env, const PromptCond& c, con
     float* Q = N1 + (size_t)nq * d;
     float* A = Q + (size_t)nq * d;
     float* P = A + (size_t)nq * d;
-    pm->host_spk.assign(c.speaker_emb, c.speaker_emb + pm->spk_dim);
-    PHIP(hipMemcpyAsync(spk, pm->host_spk.data(), (size_t)pm->spk_dim * 4, hipMemcpyHostToDevice, st));
+    pm->hold_spk.emplace_back(c.speaker_emb, c.speaker_emb + pm->spk_dim);
+    PHIP(hipMemcpyAsync(spk, pm->hold_spk.back().data(), (size_t)pm->spk_dim * 4, hipMemcpyHostToDevice, st));
 
     float* row0 = out_dev;
     // speaker projection (R/t3.R:285-286)

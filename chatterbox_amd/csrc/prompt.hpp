@@ -35,6 +35,10 @@ struct PromptCond {
 // 0 = loaded, 1 = the checkpoint has no prompt tensors (*out = nullptr, not an error), < 0 = malformed (err filled)
 int prompt_load(const SafeTensorsFile& st, int variant, int d, PromptModel** out, std::string& err);
 void prompt_free(PromptModel* pm);
+// start of a batch of prompt_build calls: sizes the staging arenas for `total_ids` token ids (conditioning + text +
+// start / stop + BOS, summed over the batch) and n_utt speaker vectors.  The stream must be drained (the previous
+// batch's uploads and kernels done) before this is called.
+int prompt_batch_begin(PromptModel* pm, size_t total_ids, int n_utt, std::string& err);
 // shape of the prompt these inputs give: rows (2 with CFG on the Llama variant), S0, conditioning length
 int prompt_shape(const PromptModel* pm, const PromptEnv& env, const PromptCond& c, int n_text, float cfg_weight, int* rows,
                  int* s0, int* len_cond, std::string& err);

@@ -1611,10 +1611,11 @@ static int build_prompts(t3mi_model* m, int n_utt, const t3mi_cond* conds, const
     ptrs.assign(n_utt, nullptr);
     s0.assign(n_utt, 0);
     std::vector<size_t> off(n_utt);
-    size_t tot = 0;
+    size_t tot = 0, total_ids = 0;
     int rows = 1;
     for (int u = 0; u < n_utt; ++u) {
         int r = 0, lc = 0;
+        total_ids += (size_t)std::max(conds[u].n_cond_tokens, 0) + (size_t)std::max(n_text[u], 0) + 3;
         const int rc = t3mi::prompt_shape(m->prompt, env, prompt_cond(&conds[u]), n_text[u], cfg_weight, &r, &s0[u], &lc, err);
         if (rc) return fail(rc, "utterance " + std::to_string(u) + ": " + err);
         rows = r;
@@ -1623,6 +1624,10 @@ static int build_prompts(t3mi_model* m, int n_utt, const t3mi_cond* conds, const
     }
     // the previous call's prefill may still read the old buffer: finish it before the buffer is replaced
     HIPCHK(hipStreamSynchronize(m->stream));
+    {
+        const int rc = t3mi::prompt_batch_begin(m->prompt, total_ids, n_utt, err);
+        if (rc) return fail(rc, err);
+    }
     if (m->prompt_buf.bytes < tot * 4) HIPCHK(m->prompt_buf.alloc(tot * 4));
     for (int u = 0; u < n_utt; ++u) {
         float* dst = m->prompt_buf.as<float>() + off[u];
