@@ -45,9 +45,10 @@ struct GemmF32 {
     using AT = float;
     static constexpr int KB = 16;  // k elements per k-block
     using Frag = float4;
-    __device__ static __forceinline__ Frag load(const void* base, size_t elem) {
+    __device__ static __forceinline__ Frag loadA(const void* base, size_t elem) {
         return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + elem);
     }
+    __device__ static __forceinline__ Frag loadW(const void* base, size_t elem) { return loadA(base, elem); }
     __device__ static __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
@@ -56,13 +57,29 @@ struct GemmF32 {
         return c;
     }
 };
+// bf16 weight storage with fp32 activation rows: the weights are widened in registers and every product is an exact
+// fp32 fma, i.e. the arithmetic of the <= 4-row GEMV kernels on bf16 weights.  Used for the prompt prefill of
+// sessions that decode on the GEMV path, so prefill and decode see the same numerics (weights rounded, nothing else).
+struct GemmBF16W {
+    using AT = float;
+    static constexpr int KB = 16;
+    using Frag = float4;
+    __device__ static __forceinline__ Frag loadA(const void* base, size_t elem) { return GemmF32::loadA(base, elem); }
+    __device__ static __forceinline__ Frag loadW(const void* base, size_t elem) {
+        const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(base) + elem);
+        return float4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                      __uint_as_float(u.y & 0xFFFF0000u)};
+    }
+    __device__ static __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) { return GemmF32::mma(a, b, c); }
+};
 struct GemmBF16 {
     using AT = uint16_t;
     static constexpr int KB = 32;
     using Frag = bf16x8;
-    __device__ static __forceinline__ Frag load(const void* base, size_t elem) {
+    __device__ static __forceinline__ Frag loadA(const void* base, size_t elem) {
         return *reinterpret_cast<const bf16x8*>(static_cast<const uint16_t*>(base) + elem);
     }
+    __device__ static __forceinline__ Frag loadW(const void* base, size_t elem) { return loadA(base, elem); }
     __device__ static __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
@@ -118,9 +135,9 @@ __global__ __launch_bounds__(KS * 64) void mfma_gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int j = (j0 + u < nkb) ? j0 + u : nkb - 1;
-            bs[u] = G::load(a.W, wbase + (size_t)j * KB);
+            bs[u] = G::loadW(a.W, wbase + (size_t)j * KB);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) as[u][mt] = G::load(a.A, abase[mt] + (size_t)j * KB);
+            for (int mt = 0; mt < MT; ++mt) as[u][mt] = G::loadA(a.A, abase[mt] + (size_t)j * KB);
         }
     };
     auto compute_stage = [&](int j0, typename G::Frag (&bs)[UN], typename G::Frag (&as)[UN][MT]) {
@@ -819,6 +836,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
             case EPI_ROPE_KV: return launch_gemm_rows_bf16<EPI_ROPE_KV>(a, s);
         }
     }
+    if (wdtype == 2) return launch_gemm_g<GemmBF16W>(a, epilogue, s);   // bf16 weights, fp32 activation rows
     return wdtype == 1 ? launch_gemm_g<GemmBF16>(a, epilogue, s) : launch_gemm_g<GemmF32>(a, epilogue, s);
 }
 

@@ -172,7 +172,8 @@ size_t sampler_lds_bytes(int V);
 
 // once per device (current device), before the first launch
 hipError_t init_device();
-// wdtype: 0 fp32, 1 bf16.  All launches are asynchronous on `s`.
+// wdtype: 0 fp32, 1 bf16 (launch_gemm: with bf16 activation rows; 2 = bf16 weights with fp32 activation rows).
+// All launches are asynchronous on `s`.
 hipError_t launch_gemv(const GemvArgs& a, int epilogue, int wdtype, hipStream_t s);
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t s);
 hipError_t launch_prefill_embed(const EmbedArgs& a, hipStream_t s);

@@ -624,11 +624,15 @@ struct GemmCtx {
     // K-split residual GEMM whose partial slabs are still to be folded into x (by the next norm launch)
     int pend_ks = 0;
     const float* pend_bias = nullptr;
+    // bf16 weight storage with fp32 activation rows (exact fp32 products, the arithmetic of the GEMV path): the prefill
+    // of sessions that decode with <= 4 rows
+    bool act_f32 = false;
 };
 
 int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
     const int d = m->d, F = m->F, H = m->H;
-    const int abf = m->wdtype == T3MI_W_BF16 ? 1 : 0;
+    const int abf = (m->wdtype == T3MI_W_BF16 && !c.act_f32) ? 1 : 0;
+    const int wdt = (m->wdtype == T3MI_W_BF16 && c.act_f32) ? 2 : m->wdtype;   // launch_gemm's operand-type selector
     const bool turbo = m->variant == T3MI_VARIANT_TURBO;
     const size_t layer_kv = (size_t)s->rows * H * s->max_len * 64 * (s->kv_bf16 ? 2 : 4);   // bytes
     hipStream_t st = m->stream;
@@ -647,7 +651,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
             a.rope_cos = m->rope_cos.as<float>(); a.rope_sin = m->rope_sin.as<float>();
             a.q = c.q; a.kcache = kc; a.vcache = vc; a.kv_bf16 = s->kv_bf16 ? 1 : 0; a.n_heads = H; a.max_len = s->max_len;
             if (turbo) { a.bias = lw.b_qkv; a.rope = 0; }
-            HIPCHK(t3k::launch_gemm(a, t3k::EPI_ROPE_KV, m->wdtype, st));
+            HIPCHK(t3k::launch_gemm(a, t3k::EPI_ROPE_KV, wdt, st));
         }
         if (tm) tm->mark(K_QKV);
         {
@@ -665,7 +669,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
             int ks = 1;
             a.ks_out = &ks;
-            HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, m->wdtype, st));
+            HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, wdt, st));
             c.pend_ks = ks > 1 ? ks : 0;
             c.pend_bias = lw.b_o;
         }
@@ -677,7 +681,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
             t3k::GemmArgs a;
             a.W = lw.wgu; a.A = c.xn; a.M = c.M; a.N = turbo ? F : 2 * F; a.K = d; a.yact = c.hact;
             a.bias = lw.b_fc;
-            HIPCHK(t3k::launch_gemm(a, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, m->wdtype, st));
+            HIPCHK(t3k::launch_gemm(a, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, wdt, st));
         }
         if (tm) tm->mark(K_GATEUP);
         {
@@ -687,7 +691,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
             int ks = 1;
             a.ks_out = &ks;
-            HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, m->wdtype, st));
+            HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, wdt, st));
             c.pend_ks = ks > 1 ? ks : 0;
             c.pend_bias = lw.b_down;
         }
@@ -1238,10 +1242,12 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
 
     // ---- prefill (R/t3.R:505): all prompt positions of all rows as ONE list of (row, position) items through
     // the MFMA GEMM path (causality = each item attends to cache slots <= its own position; Q12's -65504
-    // mask contributes exactly 0 in fp32).  bf16 weights with <= 4 rows keep fp32 activations and run the
-    // decode kernels one position at a time instead (T3MI_PREFILL=token forces that path).
+    // mask contributes exactly 0 in fp32).  Sessions that decode on the GEMV path with bf16 weights keep fp32
+    // activation rows here too (GemmBF16W), so prefill and decode share one arithmetic.  T3MI_PREFILL=token runs
+    // the decode kernels one position at a time instead.
     const char* pfenv = std::getenv("T3MI_PREFILL");
-    bool gemm_prefill = (m->wdtype == T3MI_W_F32) || s->gemm_mode;
+    bool gemm_prefill = true;
+    const bool pf_act_f32 = m->wdtype == T3MI_W_BF16 && !s->gemm_mode;
     if (pfenv && std::strcmp(pfenv, "token") == 0) gemm_prefill = false;
     if (pfenv && std::strcmp(pfenv, "gemm") == 0) gemm_prefill = true;
     if (s->kv_bf16) gemm_prefill = true;   // the one-position decode kernels write fp32 cache slots
@@ -1253,7 +1259,7 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         std::vector<const float*> last(rows);
         size_t it = 0;
         DevBuf xpf, qpf, xnpf, aopf, hpf, dsrc, dpos, drow, dlast;
-        const size_t as = m->wdtype == T3MI_W_BF16 ? 2 : 4;
+        const size_t as = (m->wdtype == T3MI_W_BF16 && !pf_act_f32) ? 2 : 4;
         HIPCHK(xpf.alloc(items * d * 4));
         for (int r = 0; r < (int)rows; ++r) {
             const int u = r / rpu;
@@ -1281,6 +1287,7 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         c.M = (int)items; c.x = xpf.as<float>(); c.q = qpf.as<float>();
         c.xn = xnpf.p; c.attn_out = aopf.p; c.hact = hpf.p;
         c.posmap = dpos.as<int>(); c.rowmap = drow.as<int>();
+        c.act_f32 = pf_act_f32;
         if ((rc = run_layers_gemm(m, s.get(), c, nullptr))) return rc;
         if ((rc = fold_pending(m, s.get(), c))) return rc;
         // the last prompt position of every row feeds the first speech-head evaluation

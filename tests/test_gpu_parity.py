@@ -235,3 +235,26 @@ def test_prefill_paths_agree(tiny, monkeypatch):
     assert rel_err(res["gemm"], res["token"]) < 1e-5
     ref = O.t3_inference(om, emb, O.SampleParams(max_new_tokens=1, top_p=0.0), mask_stop=True)
     assert rel_err(res["gemm"], ref.raw_logits[0]) < LOGIT_TOL
+
+
+def test_bf16_prefill_paths_agree(monkeypatch):
+    """bf16 weight storage, GEMV-path session: the batched prefill (bf16 weights widened in registers, fp32
+    activation rows, fp32 cache) and the one-position-at-a-time prefill through the decode kernels are the same
+    arithmetic up to summation order, so the first logits agree to fp32 rounding -- and so do the greedy tokens."""
+    dims = synth.TINY
+    model = cb.load_t3(synth.ensure_checkpoint(dims, 1234), device=0, dtype="bf16",
+                       start_speech_token=dims.start_speech_token, stop_speech_token=dims.stop_speech_token)
+    try:
+        emb = synth.synth_embeds(2, 37, dims.hidden_size, 72)
+        res, toks = {}, {}
+        for mode in ("gemm", "token"):
+            monkeypatch.setenv("T3MI_PREFILL", mode)
+            with cb.Session(model, [emb], max_new_tokens=8, top_p=0.0, mask_stop=True) as s:
+                res[mode] = s.logits()
+                s.decode(8)
+                toks[mode] = s.tokens(0)
+        monkeypatch.delenv("T3MI_PREFILL")
+        assert rel_err(res["gemm"], res["token"]) < 1e-5
+        assert np.array_equal(toks["gemm"], toks["token"])
+    finally:
+        model.close()
