@@ -79,6 +79,46 @@ def test_tiny_sampling_tail_both_reference_rules(tiny_peaked, variant, sampler):
     assert 1 < np.median(sizes) < 200          # the distribution really is peaked
 
 
+@pytest.mark.parametrize("variant,sampler,top_p", [("r", _lib.SAMPLER_R, 0.8), ("cpp", _lib.SAMPLER_CPP, 0.8),
+                                                   ("r", _lib.SAMPLER_R, 0.9995)])
+def test_tiny_sampling_tail_without_min_p(tiny_peaked, variant, sampler, top_p):
+    """min_p = 0: nothing is zeroed before the sort, so the top-p prefilter alone decides how much of the
+    vocabulary is sorted (top_p .8: a few entries; .9995 on this model: the mass threshold is not reached and the
+    full support is sorted).  Distribution and draw must equal the full-sort oracle's."""
+    dims, model, om = tiny_peaked
+    emb = synth.synth_embeds(2, 9, dims.hidden_size, 34)
+    n = 12
+    cache = 350 if variant == "cpp" else 0
+    p = O.SampleParams(max_new_tokens=n, seed=5, variant=variant, top_p=top_p, min_p=0.0, max_cache_len=cache)
+    ref = O.t3_inference(om, emb, p, mask_stop=True)
+    with cb.Session(model, [emb], max_new_tokens=n, seed=5, top_p=top_p, min_p=0.0, sampler=sampler,
+                    max_cache_len=cache, mask_stop=True, forced=np.array(ref.tokens)) as s:
+        for i in range(n):
+            s.decode(1)
+            ids, pr = s.dist(0)
+            if assert_dist_close(ids, pr, ref.tails[i]):
+                assert draw_is_consistent(int(s.drawn()[0]), ref.tails[i]), f"draw differs at step {i}"
+
+
+def test_tiny_top_p_one_keeps_the_support(tiny_peaked):
+    """top_p = 1, min_p = 0: no entry is filtered except where the float cumulative sum itself rounds above 1.0
+    (R/t3.R:557: `cumsum > top_p`), which happens deep in the tail (probabilities ~1e-8) and on either side of the
+    same rounding in the two implementations -- so the head of the distribution is compared, not the tail."""
+    dims, model, om = tiny_peaked
+    emb = synth.synth_embeds(2, 9, dims.hidden_size, 36)
+    p = O.SampleParams(max_new_tokens=2, seed=5, top_p=1.0, min_p=0.0)
+    ref = O.t3_inference(om, emb, p, mask_stop=True)
+    with cb.Session(model, [emb], max_new_tokens=2, seed=5, top_p=1.0, min_p=0.0, mask_stop=True,
+                    forced=np.array(ref.tokens)) as s:
+        s.decode(1)
+        ids, pr = s.dist(0)
+    t = ref.tails[0]
+    assert len(ids) > dims.speech_vocab // 2
+    k = 64
+    assert list(ids[:k]) == [int(i) for i in t.sorted_idx[:k]]
+    assert np.allclose(pr[:k], np.asarray(t.sorted_probs[:k], dtype=np.float64), rtol=2e-3)
+
+
 def test_tiny_free_running_sampled_tokens(tiny_peaked):
     """No teacher forcing: the whole sampled stream equals the oracle's up to the first step whose
     draw sits on a CDF step (after which the histories legitimately diverge)."""
