@@ -16,6 +16,19 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef HAVE_T3MI
+/* configure found no hipcc: same behaviour as the reference's build without libtorch
+ * (src/t3_decode.cpp:432-446) -- the package loads, the backend raises when called. */
+static SEXP no_backend(void) {
+    Rf_error("chatterbox was built without the MI355X T3 backend (hipcc not found at configure time)");
+    return R_NilValue;
+}
+SEXP t3mi_r_open(SEXP a, SEXP b, SEXP c, SEXP d) { return no_backend(); }
+SEXP t3mi_r_close(SEXP a) { return R_NilValue; }
+SEXP t3mi_r_generate(SEXP a, SEXP b, SEXP c, SEXP d) { return no_backend(); }
+SEXP t3mi_r_generate_batch(SEXP a, SEXP b, SEXP c, SEXP d) { return no_backend(); }
+SEXP t3mi_r_generate_tokens(SEXP a, SEXP b, SEXP c, SEXP d) { return no_backend(); }
+#else
 #include "t3mi.h"
 
 static double cfg_real(SEXP list, const char* name, double dflt, int required) {
@@ -253,6 +266,8 @@ SEXP t3mi_r_generate_tokens(SEXP model, SEXP conds, SEXP texts, SEXP cfg) {
     UNPROTECT(1);
     return res;
 }
+
+#endif /* HAVE_T3MI */
 
 static const R_CallMethodDef call_methods[] = {
     {"t3mi_r_open", (DL_FUNC)&t3mi_r_open, 4},
