@@ -7,7 +7,7 @@
 #include <memory>
 #include <vector>
 
-#include "../../include/t3mi.h"
+#include "t3mi.h"
 #include "kernels.hpp"
 
 namespace t3mi {

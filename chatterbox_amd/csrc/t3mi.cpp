@@ -4,7 +4,7 @@
 // the KV slabs and all per-session state in HBM; drives the decode step as a replayed HIP graph
 // so that a step needs no host synchronisation (the reference syncs 2-3x per token:
 // R/t3.R:530,574 ; src/t3_decode.cpp:339,361-362).
-#include "../../include/t3mi.h"
+#include "t3mi.h"
 
 #include <hip/hip_runtime_api.h>
 
