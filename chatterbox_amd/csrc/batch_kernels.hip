@@ -545,11 +545,13 @@ __device__ __forceinline__ int tile32_feature(int t, int r32, int N) {
     return 32 * t + r32;
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_rows_bf16_kernel(GemmArgs a) {
-    constexpr int KC = 128, LD = KC + 8;   // row stride 272 B: the 16 rows of a fragment read fall in distinct banks
+template <int EPI, typename T>
+__global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
+    constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte piece: 8 (bf16) or 4 (fp32)
+    constexpr int KC = 16 * E, LD = KC + E;  // 256-byte step rows, row stride 272 B: the 16 rows of a fragment read fall in distinct banks
     constexpr int kRows = 160;             // 128 activation rows + 32 weight rows per step
-    extern __shared__ __attribute__((aligned(16))) uint16_t tl[];   // [2][kRows][LD]
+    extern __shared__ __attribute__((aligned(16))) unsigned char tl_raw[];
+    T* tl = reinterpret_cast<T*>(tl_raw);   // [2][kRows][LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = lane & 15, g = lane >> 4;
     const int tile = blockIdx.x, m0 = blockIdx.y * 128, kz = blockIdx.z;
@@ -559,27 +561,27 @@ __global__ __launch_bounds__(512) void gemm_rows_bf16_kernel(GemmArgs a) {
                                   ? a.dbg + 4 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
     if (dbg) dbg[0] = wall_clock64();
     const int kbeg = kz * S * KC;
-    const uint16_t* Wp = static_cast<const uint16_t*>(a.W);
-    const uint16_t* Ap = static_cast<const uint16_t*>(a.A);
+    const T* Wp = static_cast<const T*>(a.W);
+    const T* Ap = static_cast<const T*>(a.A);
 
     // staging: a step's tile is 160 rows x 256 B; thread t moves the 16 B piece t & 15 of rows (t >> 4) + 32 p,
     // p = 0..4, so 16 consecutive lanes fetch one whole 256-byte run (rows 0..127 activations, 128..159 weights).
     // Fetching the activation rows straight into MFMA fragments instead (16 rows x 64 B per instruction) asks L2 for
     // every line four times: measured 3-4x slower at 128 rows.
     const int srow = tid >> 4, spiece = tid & 15;
-    const uint16_t* src[5];
+    const T* src[5];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         int r = m0 + p * 32 + srow;
         r = r < a.M ? r : a.M - 1;
-        src[p] = Ap + (size_t)r * K + kbeg + spiece * 8;
+        src[p] = Ap + (size_t)r * K + kbeg + spiece * E;
     }
     {
         int sf = tile32_feature<EPI>(tile, srow, a.N);
         sf = sf < a.N ? sf : a.N - 1;
-        src[4] = Wp + (size_t)sf * K + kbeg + spiece * 8;
+        src[4] = Wp + (size_t)sf * K + kbeg + spiece * E;
     }
-    const int soff = srow * LD + spiece * 8;
+    const int soff = srow * LD + spiece * E;
     const bool live = m0 + wave * 16 < a.M;
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(512) void gemm_rows_bf16_kernel(GemmArgs a) {
                 const int ua = (u + 1) % kDA, uw = (u + 1) % kDW;
                 // tile of step s+1 -> the LDS buffer last read in step s-1; then refill the ring slots
                 if (s + 1 < S) {
-                    uint16_t* dst = tl + ((s + 1) & 1) * (kRows * LD) + soff;
+                    T* dst = tl + ((s + 1) & 1) * (kRows * LD) + soff;
 #pragma unroll
                     for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(dst + p * 32 * LD) = ra[ua][p];
                     *reinterpret_cast<uint4*>(dst + 4 * 32 * LD) = rw[uw];
@@ -626,16 +628,32 @@ __global__ __launch_bounds__(512) void gemm_rows_bf16_kernel(GemmArgs a) {
                 }
                 if (s + 1 + kDW < S) rw[uw] = *reinterpret_cast<const uint4*>(src[4] + (size_t)(s + 1 + kDW) * KC);
                 if (live) {
-                    const uint16_t* tb = tl + (s & 1) * (kRows * LD);
-                    const uint16_t* ab = tb + (wave * 16 + nl) * LD + g * 32;
-                    const uint16_t* wb = tb + (128 + nl) * LD + g * 32;
+                    // lane (nl, g) reads the 64 bytes g of its row: piece j of them feeds MFMA (group) j of the step
+                    const T* tb = tl + (s & 1) * (kRows * LD);
+                    const T* ab = tb + (wave * 16 + nl) * LD + g * (4 * E);
+                    const T* wb = tb + (128 + nl) * LD + g * (4 * E);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const bf16x8 av = *reinterpret_cast<const bf16x8*>(ab + j * 8);
-                        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wb + j * 8);
-                        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wb + 16 * LD + j * 8);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc1, 0, 0, 0);
+                        if constexpr (sizeof(T) == 2) {
+                            const bf16x8 av = *reinterpret_cast<const bf16x8*>(ab + j * 8);
+                            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wb + j * 8);
+                            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wb + 16 * LD + j * 8);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc1, 0, 0, 0);
+                        } else {
+                            // fp32 operands: exact fp32 fma chains (v_mfma_f32_16x16x4_f32, one k per lane group)
+                            const float4 av = *reinterpret_cast<const float4*>(ab + j * 4);
+                            const float4 b0 = *reinterpret_cast<const float4*>(wb + j * 4);
+                            const float4 b1 = *reinterpret_cast<const float4*>(wb + 16 * LD + j * 4);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1.y, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b0.z, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1.z, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0.w, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, acc1, 0, 0, 0);
+                        }
                     }
                 }
                 __syncthreads();
@@ -668,15 +686,15 @@ __global__ __launch_bounds__(512) void gemm_rows_bf16_kernel(GemmArgs a) {
                 }
             }
         } else if (EPI == EPI_GELU) {   // gelu_tanh(c_fc(x) + b)  (R/t3.R:1303-1304)
-            uint16_t* yo = static_cast<uint16_t*>(a.yact) + (size_t)mi * a.N;
+            T* yo = static_cast<T*>(a.yact) + (size_t)mi * a.N;
             if (a.bias != nullptr) { v0 = __fadd_rn(v0, a.bias[f0]); v1 = __fadd_rn(v1, a.bias[f1]); }
             const float i0 = 0.7978845608028654f * (v0 + 0.044715f * v0 * v0 * v0);
             const float i1 = 0.7978845608028654f * (v1 + 0.044715f * v1 * v1 * v1);
-            if (f0 < a.N) yo[f0] = f2bf(0.5f * v0 * (1.0f + tanhf(i0)));
-            if (f1 < a.N) yo[f1] = f2bf(0.5f * v1 * (1.0f + tanhf(i1)));
+            if (f0 < a.N) Act<T>::store(yo + f0, 0.5f * v0 * (1.0f + tanhf(i0)));
+            if (f1 < a.N) Act<T>::store(yo + f1, 0.5f * v1 * (1.0f + tanhf(i1)));
         } else if (EPI == EPI_SWIGLU) {   // silu(gate) * up  (R/llama.R:302, 307)
             const float sg = 1.0f / (1.0f + expf(-v0));
-            static_cast<uint16_t*>(a.yact)[(size_t)mi * (a.N >> 1) + 16 * tile + nl] = f2bf(__fmul_rn(__fmul_rn(v0, sg), v1));
+            Act<T>::store(static_cast<T*>(a.yact) + (size_t)mi * (a.N >> 1) + 16 * tile + nl, __fmul_rn(__fmul_rn(v0, sg), v1));
         } else {  // EPI_ROPE_KV
             const int pos = a.posmap[mi];
             if (pos < 0) continue;
@@ -713,7 +731,7 @@ __global__ __launch_bounds__(512) void gemm_rows_bf16_kernel(GemmArgs a) {
     if (dbg) dbg[3] = wall_clock64();
 }
 
-// y[m][i] = resid[m][i] + bias[i] + sum_s part[s][m][i], s ascending (the K-split of gemm_rows_bf16_kernel).
+// y[m][i] = resid[m][i] + bias[i] + sum_s part[s][m][i], s ascending (the K-split of gemm_rows_kernel).
 // grid (M, N / 256): every thread fetches its <= 8 partials at once, then adds them in order.
 __global__ __launch_bounds__(256) void fold_partials_kernel(float* __restrict__ y, const float* __restrict__ resid,
                                                             const float* __restrict__ part, int ks, const float* __restrict__ bias,
@@ -733,8 +751,9 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(float* __restrict__ 
     y[o] = resid != nullptr ? __fadd_rn(r, v) : v;
 }
 
-template <int EPI>
-hipError_t launch_gemm_rows_bf16(const GemmArgs& a, hipStream_t s) {
+template <int EPI, typename T>
+hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s) {
+    constexpr int KC = 16 * (16 / (int)sizeof(T));   // the kernel's step: 128 (bf16) or 64 (fp32) k
     int tiles;
     if (EPI == EPI_ROPE_KV) tiles = (a.N / kHeadDim) * 2;
     else if (EPI == EPI_SWIGLU) tiles = a.N / 32;
@@ -743,23 +762,23 @@ hipError_t launch_gemm_rows_bf16(const GemmArgs& a, hipStream_t s) {
     int ks = 1;
     if ((EPI == EPI_RESID || EPI == EPI_STORE) && a.part != nullptr) {
         // few feature tiles: split K over blocks until the launch has ~192 blocks (steps per block stay even)
-        while (ks < 8 && (long long)tiles * chunks * ks < 192 && a.K % (256 * ks * 2) == 0 &&
+        while (ks < 8 && (long long)tiles * chunks * ks < 192 && a.K % (2 * KC * ks * 2) == 0 &&
                (size_t)(2 * ks) * a.M * a.N <= a.part_floats)
             ks *= 2;
     }
     constexpr int lds = 2 * 160 * (128 + 8) * 2;   // 87,040 B: two step tiles
     // the attribute belongs to the (kernel, device) pair: one flag per EPI instantiation and device
-    static bool attr_done[64] = {};
+    static bool attr_done[64] = {};   // (static in a function template: one array per <EPI, T>)
     int dev = 0;
     hipError_t ed = hipGetDevice(&dev);
     if (ed != hipSuccess) return ed;
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_bf16_kernel<EPI>),
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e0 != hipSuccess) return e0;
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
-    hipLaunchKernelGGL(gemm_rows_bf16_kernel<EPI>, dim3(tiles, chunks, ks), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((gemm_rows_kernel<EPI, T>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     hipError_t e = hipGetLastError();
     if (a.ks_out != nullptr) *a.ks_out = ks;
     if (e != hipSuccess || ks == 1) return e;
@@ -827,13 +846,24 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
          (a.rope && (!a.rope_cos || !a.rope_sin))))
         return hipErrorInvalidValue;
     static const bool gen1 = [] { const char* v = getenv("T3MI_GEMM_GEN1"); return v && v[0] == '1'; }();
-    if (wdtype == 1 && !gen1 && a.K % 256 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0)) {
-        switch (epilogue) {
-            case EPI_STORE: return launch_gemm_rows_bf16<EPI_STORE>(a, s);
-            case EPI_RESID: return launch_gemm_rows_bf16<EPI_RESID>(a, s);
-            case EPI_GELU: return launch_gemm_rows_bf16<EPI_GELU>(a, s);
-            case EPI_SWIGLU: return launch_gemm_rows_bf16<EPI_SWIGLU>(a, s);
-            case EPI_ROPE_KV: return launch_gemm_rows_bf16<EPI_ROPE_KV>(a, s);
+    // second-generation kernel: bf16 operands, or fp32 operands (T3MI_GEMM_GEN1=1 selects the first generation)
+    if ((wdtype == 1 || wdtype == 0) && !gen1 && a.K % 256 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0)) {
+        if (wdtype == 1) {
+            switch (epilogue) {
+                case EPI_STORE: return launch_gemm_rows<EPI_STORE, uint16_t>(a, s);
+                case EPI_RESID: return launch_gemm_rows<EPI_RESID, uint16_t>(a, s);
+                case EPI_GELU: return launch_gemm_rows<EPI_GELU, uint16_t>(a, s);
+                case EPI_SWIGLU: return launch_gemm_rows<EPI_SWIGLU, uint16_t>(a, s);
+                case EPI_ROPE_KV: return launch_gemm_rows<EPI_ROPE_KV, uint16_t>(a, s);
+            }
+        } else {
+            switch (epilogue) {
+                case EPI_STORE: return launch_gemm_rows<EPI_STORE, float>(a, s);
+                case EPI_RESID: return launch_gemm_rows<EPI_RESID, float>(a, s);
+                case EPI_GELU: return launch_gemm_rows<EPI_GELU, float>(a, s);
+                case EPI_SWIGLU: return launch_gemm_rows<EPI_SWIGLU, float>(a, s);
+                case EPI_ROPE_KV: return launch_gemm_rows<EPI_ROPE_KV, float>(a, s);
+            }
         }
     }
     if (wdtype == 2) return launch_gemm_g<GemmBF16W>(a, epilogue, s);   // bf16 weights, fp32 activation rows

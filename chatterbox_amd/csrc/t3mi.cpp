@@ -1166,7 +1166,12 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         HIPCHK(s->xn.alloc(rows * d * as));
         HIPCHK(s->attn_out.alloc(rows * d * as));
         HIPCHK(s->hact.alloc(rows * F * as));
-        HIPCHK(s->gpart.alloc(s->gemm_mode ? 8 * rows * d * 4 : 16));
+        // K-split partial slabs: the decode rows of a many-row session, and the prompt items of a short prefill
+        // (few row chunks: the residual GEMMs need the K split to fill the chip)
+        size_t items = 0;
+        for (int u = 0; u < n_utt; ++u) items += (size_t)rpu * s0[u];
+        const size_t part_rows = std::max<size_t>(s->gemm_mode ? rows : 0, items <= 1024 ? items : 0);
+        HIPCHK(s->gpart.alloc(part_rows ? 8 * part_rows * d * 4 : 16));
     }
     s->pf_on = m->pf_ok && !s->gemm_mode && rows <= 4;
     s->ikpf = m->ikpf_ok && !s->pf_on && !s->gemm_mode && rows <= 4;

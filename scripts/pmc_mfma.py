@@ -14,8 +14,8 @@ acc = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(set)
 for r in rows:
     n = r["Kernel_Name"]
-    if "gemm_rows_bf16_kernel<" in n:
-        k = "gemm_rows_bf16<" + n.split("gemm_rows_bf16_kernel<")[1].split(">")[0] + ">"
+    if "gemm_rows_kernel<" in n:
+        k = "gemm_rows<" + n.split("gemm_rows_kernel<")[1].split(">")[0] + ">"
     elif "attn_rows_kernel" in n:
         k = "attn_rows"
     elif "rmsnorm_rows" in n:
