@@ -847,7 +847,10 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
         return hipErrorInvalidValue;
     static const bool gen1 = [] { const char* v = getenv("T3MI_GEMM_GEN1"); return v && v[0] == '1'; }();
     // second-generation kernel: bf16 operands, or fp32 operands (T3MI_GEMM_GEN1=1 selects the first generation)
-    if ((wdtype == 1 || wdtype == 0) && !gen1 && a.K % 256 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0)) {
+    // fp32 operands take it from 64 rows up: its block is 128 rows x 32 features whatever M is, and the exact-fp32 MFMA is
+    // 16x slower than the bf16 one, so with few rows (one live wave per block) the first generation's 16-feature tiles
+    // with K split over the waves win (8 rows, Turbo batched: 5156 vs 3516 tok/s)
+    if ((wdtype == 1 || (wdtype == 0 && a.M >= 64)) && !gen1 && a.K % 256 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0)) {
         if (wdtype == 1) {
             switch (epilogue) {
                 case EPI_STORE: return launch_gemm_rows<EPI_STORE, uint16_t>(a, s);

@@ -298,3 +298,32 @@ def test_bf16_prefill_paths_agree(monkeypatch):
         assert np.array_equal(toks["gemm"], toks["token"])
     finally:
         model.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", LOGIT_TOL), ("bf16", BF16_LOGIT_TOL)])
+def test_tiny_80_rows_128_row_gemm_tiles(dtype, tol):
+    """40 utterances x CFG pair = 80 activation rows: the decode linears run on the 128-row LDS-staged MFMA tiles
+    (fp32 operands: exact fp32 MFMA, from 64 rows up; bf16 operands with the bf16 KV cache), ragged prompts,
+    K-split residual GEMMs folded in the row norms.  Every utterance is teacher-forced with its own oracle
+    stream: logits of every step within the dtype's bar; fp32 also reproduces the greedy tokens unforced."""
+    dims = synth.TINY
+    om = oracle_model(dims, 1234)
+    model = cb.load_t3(synth.ensure_checkpoint(dims, 1234), device=0, dtype=dtype,
+                       start_speech_token=dims.start_speech_token, stop_speech_token=dims.stop_speech_token)
+    try:
+        U, n = 40, 6
+        embs = [synth.synth_embeds(2, 4 + (7 * u) % 23, dims.hidden_size, 500 + u) for u in range(U)]
+        refs = [O.t3_inference(om, e, O.SampleParams(max_new_tokens=n, top_p=0.0), mask_stop=True) for e in embs]
+        forced = np.array([r.tokens for r in refs])
+        with cb.Session(model, embs, max_new_tokens=n, top_p=0.0, mask_stop=True, forced=forced) as s:
+            for i in range(n):
+                lg = s.logits()
+                for u in range(U):
+                    assert rel_err(lg[2 * u:2 * u + 2], refs[u].raw_logits[i]) < tol, f"{dtype} utt {u} step {i}"
+                s.decode(1)
+        if dtype == "f32":
+            outs = cb.t3_inference_batch(model, embs, max_new_tokens=n, top_p=0.0, mask_stop=True)
+            for u in range(U):
+                assert list(outs[u]) == refs[u].tokens, f"utt {u}"
+    finally:
+        model.close()
