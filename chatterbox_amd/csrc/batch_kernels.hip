@@ -526,16 +526,15 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* const* __
 // ---- bf16 many-row GEMM, second generation ------------------------------------------------------------------
 // y[M,N] = A[M,K] * W[N,K]^T with bf16 operands, fp32 accumulate, for up to 128 rows per block.
 //
-// Block = 8 waves = 128 rows x 32 output features x one K range.  A step's tile (128 activation rows + 32 weight
-// rows, 256 B each, whole lines: 16 consecutive lanes fetch one row's run; 128 k in bf16, 64 k in fp32) goes
-// global -> registers -> LDS once per block and is shared by the 8 waves; register rings keep kDA steps of
-// activations (from L2) and kDW steps of weights (from HBM: for K <= 1024 the block's whole weight slice) in flight.
-// Wave (rg, kh) computes the 32 rows of row group rg (two 16-row tiles) x both 16-feature sub-tiles over k half kh
-// of every step -- 4 accumulator tiles, 64 KB of LDS fragment reads per step and block (a rows-only split over the
-// waves reads 96 KB: every wave would re-read both weight sub-tiles over the whole step); the two halves of a row
-// group are added through LDS once, after the loop, in a fixed order.  Lane (n, g) reads the 32 bytes g of its half
-// of the row: a fixed permutation of the dot product's terms over the MFMA k slots.  The two sub-tiles hold PARTNER
-// features of the fused epilogues (gate / up, rotate_half i / i+32), so SwiGLU and RoPE finish in registers.
+// Block = 8 waves = 128 rows x 32 output features x one K range.  Wave w owns rows 16w..16w+15 and both 16-feature
+// sub-tiles, so it holds 2 accumulator tiles.  A 128-k step's tile (128 activation rows + 32 weight rows, 256 B
+// each, whole lines: 16 consecutive lanes fetch one row's run) goes global -> registers -> LDS once per block and
+// is shared by the 8 waves; register rings keep kDA steps of activations (from L2) and kDW steps of weights (from
+// HBM: for K <= 1024 the block's whole weight slice) in flight.  Lane (n, g) reads k = g*32..g*32+31 of its row
+// from LDS per step: MFMA j of the step uses k = g*32 + 8j..8j+7 from both operands, a fixed permutation of the
+// dot product's terms.  The two sub-tiles hold PARTNER features of the fused epilogues (gate / up, rotate_half
+// i / i+32), so SwiGLU and RoPE finish in registers.  Measured at 128 rows (profiles/r01_micro_gemm_m128.txt):
+// first tile in LDS after 1.4-3.8 us, ~0.65 us per step (LDS-bandwidth bound: 40 KB written + 96 KB read).
 // Residual GEMMs with few feature tiles (N = 1024) split K over blockIdx.z into fp32 partial slabs that
 // fold_partials_kernel sums in a fixed order (deterministic, no atomics).
 template <int EPI>
@@ -583,15 +582,9 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
         src[4] = Wp + (size_t)sf * K + kbeg + spiece * E;
     }
     const int soff = srow * LD + spiece * E;
-    // wave = (row group rg: 32 rows = two 16-row tiles) x (k half kh of every step); both 16-feature sub-tiles
-    const int rg = wave & 3, kh = wave >> 2;
-    const bool live = m0 + rg * 32 < a.M;
+    const bool live = m0 + wave * 16 < a.M;
 
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb) acc[rt][sb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     // register rings: the weights come from HBM (2-3 us under load) and are requested kDW steps ahead, which for the
     // decode shapes (K <= 1024 per block) is the block's whole weight slice at kernel start (default cache policy:
     // non-temporal weight loads measured 1-2 % slower here, gate_up 21.1 -> 21.7 us, down 11.3 -> 12.3); the activation rows come
@@ -635,39 +628,31 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
                 }
                 if (s + 1 + kDW < S) rw[uw] = *reinterpret_cast<const uint4*>(src[4] + (size_t)(s + 1 + kDW) * KC);
                 if (live) {
-                    // the wave takes k half kh of the step; lane (nl, g) reads the 32 bytes g of that half of its rows:
-                    // piece j of them feeds MFMA (group) j.  Each wave reads 2 row tiles + 2 weight sub-tiles of its
-                    // half: 64 KB of LDS reads per step and block instead of the 96 KB of a rows-only split.
+                    // lane (nl, g) reads the 64 bytes g of its row: piece j of them feeds MFMA (group) j of the step
                     const T* tb = tl + (s & 1) * (kRows * LD);
-                    const T* ab = tb + (rg * 32 + nl) * LD + kh * (KC / 2) + g * (2 * E);
-                    const T* wb = tb + (128 + nl) * LD + kh * (KC / 2) + g * (2 * E);
+                    const T* ab = tb + (wave * 16 + nl) * LD + g * (4 * E);
+                    const T* wb = tb + (128 + nl) * LD + g * (4 * E);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < 4; ++j) {
                         if constexpr (sizeof(T) == 2) {
+                            const bf16x8 av = *reinterpret_cast<const bf16x8*>(ab + j * 8);
                             const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wb + j * 8);
                             const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wb + 16 * LD + j * 8);
-#pragma unroll
-                            for (int rt = 0; rt < 2; ++rt) {
-                                const bf16x8 av = *reinterpret_cast<const bf16x8*>(ab + rt * 16 * LD + j * 8);
-                                acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc[rt][0], 0, 0, 0);
-                                acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc[rt][1], 0, 0, 0);
-                            }
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc1, 0, 0, 0);
                         } else {
                             // fp32 operands: exact fp32 fma chains (v_mfma_f32_16x16x4_f32, one k per lane group)
+                            const float4 av = *reinterpret_cast<const float4*>(ab + j * 4);
                             const float4 b0 = *reinterpret_cast<const float4*>(wb + j * 4);
                             const float4 b1 = *reinterpret_cast<const float4*>(wb + 16 * LD + j * 4);
-#pragma unroll
-                            for (int rt = 0; rt < 2; ++rt) {
-                                const float4 av = *reinterpret_cast<const float4*>(ab + rt * 16 * LD + j * 4);
-                                acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc[rt][0], 0, 0, 0);
-                                acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc[rt][1], 0, 0, 0);
-                                acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc[rt][0], 0, 0, 0);
-                                acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1.y, acc[rt][1], 0, 0, 0);
-                                acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b0.z, acc[rt][0], 0, 0, 0);
-                                acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1.z, acc[rt][1], 0, 0, 0);
-                                acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0.w, acc[rt][0], 0, 0, 0);
-                                acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, acc[rt][1], 0, 0, 0);
-                            }
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1.y, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b0.z, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1.z, acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0.w, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, acc1, 0, 0, 0);
                         }
                     }
                 }
@@ -676,36 +661,14 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
         }
     }
     if (dbg) dbg[2] = wall_clock64();
-    // the two k halves of a row group meet in LDS (the step tiles are dead after the loop's last barrier); the kh = 0
-    // wave adds its partner's sums in a fixed order and runs the epilogue
-    {
-        f32x4* red = reinterpret_cast<f32x4*>(tl_raw);   // [rg][rt][sub-tile][lane]
-        if (kh == 1 && live) {
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb) red[((rg * 2 + rt) * 2 + sb) * 64 + lane] = acc[rt][sb];
-        }
-        __syncthreads();
-        if (kh == 1 || !live) return;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
-                const f32x4 o = red[((rg * 2 + rt) * 2 + sb) * 64 + lane];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[rt][sb][r] = __fadd_rn(acc[rt][sb][r], o[r]);
-            }
-    }
-    // accumulator layout: row = g*4 + r of the 16-row tile, column nl of the sub-tile
+    if (!live) return;
+    // accumulator layout: row = g*4 + r of the wave's 16 rows, column nl of the sub-tile
     const int f0 = tile32_feature<EPI>(tile, nl, a.N), f1 = tile32_feature<EPI>(tile, 16 + nl, a.N);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int mi = m0 + rg * 32 + rt * 16 + g * 4 + r;
+        const int mi = m0 + wave * 16 + g * 4 + r;
         if (mi >= a.M) continue;
-        float v0 = acc[rt][0][r], v1 = acc[rt][1][r];
+        float v0 = acc0[r], v1 = acc1[r];
         if (EPI == EPI_STORE || EPI == EPI_RESID) {
             if (gridDim.z > 1) {   // K split over blocks: fp32 partial slab of this K range
                 float* pr = a.part + ((size_t)kz * a.M + mi) * a.N;
