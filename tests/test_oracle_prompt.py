@@ -95,3 +95,18 @@ def test_cond_encoder_matches_libtorch_op_for_op():
     got = O.cond_enc(w, spk, prompt, 0.5, use_perceiver=True)
     assert got.shape == want.shape == (34, d)
     assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+
+
+def test_text_start_stop_tokens_match_the_reference_fixture():
+    """outputs/t3_reference.safetensors holds the text ids upstream fed to T3 for one sentence, WITH the start / stop
+    text tokens: 255 first, 0 last (R/t3.R:14-15, 473-477) -- the constants the oracle and the library add."""
+    g = np.load(os.path.join(GOLD, "ref_tokens.npz"))
+    tt = g["text_tokens_with_sot_eot"].reshape(-1)
+    assert int(tt[0]) == O.START_TEXT_TOKEN == 255 and int(tt[-1]) == O.STOP_TEXT_TOKEN == 0
+    assert tt.size == 37 and np.all(tt[1:-1] < 704) and not np.any(tt[1:-1] == 255)
+    # S0 of that sentence under the reference's layout: 34 conditioning rows + 37 text rows + BOS = 72, the shape of
+    # initial_embeds in outputs/t3_debug.safetensors (SURVEY §8)
+    w = synth.synth_llama_weights(synth.TINY)
+    spk, cond, _ = _inputs(synth.TINY)
+    e, lc = O.prepare_input_embeds(w, spk, cond, 0.5, tt[1:-1] % synth.TINY.text_vocab, 0.5, synth.TINY.start_speech_token)
+    assert e.shape[:2] == (2, 72) and lc == 34
