@@ -327,3 +327,29 @@ def test_tiny_80_rows_128_row_gemm_tiles(dtype, tol):
                 assert list(outs[u]) == refs[u].tokens, f"utt {u}"
     finally:
         model.close()
+
+
+def test_full_size_cfg2_shape_96_steps():
+    """The benchmarked configuration itself (BASELINE configs[1]): Llama-520M shapes, the reference's real prompt
+    activations tiled to S0 = 52 (bench.py's stand-in, tests/golden/ref_prompt_embeds.npz), CFG pair, 96 decode
+    steps (cache length 52 -> 148: one to three key splits per head), teacher-forced with the oracle's greedy
+    stream: logits of every step within the fp32 bar, and the free-running greedy tokens identical."""
+    import os
+    dims = synth.FULL
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_prompt_embeds.npz"))["input_embeds"].astype(np.float32)
+    emb = np.ascontiguousarray(np.tile(g, (1, 2, 1))[:, :52, :])
+    om = oracle_model(dims, 1234)
+    n = 96
+    ref = O.t3_inference(om, emb, O.SampleParams(max_new_tokens=n, top_p=0.0), mask_stop=True)
+    model = cb.load_t3(synth.ensure_checkpoint(dims, 1234), device=0)
+    try:
+        worst = 0.0
+        with cb.Session(model, [emb], max_new_tokens=n, top_p=0.0, mask_stop=True, forced=np.array(ref.tokens)) as s:
+            for i in range(n):
+                worst = max(worst, rel_err(s.logits(), ref.raw_logits[i]))
+                s.decode(1)
+        assert worst < LOGIT_TOL, worst
+        toks = cb.t3_inference(model, emb, max_new_tokens=n, top_p=0.0)
+        assert list(toks[:n]) == ref.tokens[: len(toks[:n])] and len(toks) >= 1
+    finally:
+        model.close()
