@@ -353,3 +353,35 @@ def test_full_size_cfg2_shape_96_steps():
         assert list(toks[:n]) == ref.tokens[: len(toks[:n])] and len(toks) >= 1
     finally:
         model.close()
+
+
+def test_full_size_cfg3_shape_batch_invariance():
+    """BASELINE configs[2] at full size (64 utterances x CFG pair = 128 rows, S0 = 64) through size-independent
+    properties, since the oracle would need minutes here: (i) fp32: every sampled utterance of the batch (128-row
+    MFMA tiles, K-split residual GEMMs) produces the greedy tokens of the same utterance decoded alone (GEMV path);
+    (ii) bf16 weights + bf16 KV cache: first-step logits of all 128 rows within the bf16 bar of the fp32 batch's."""
+    dims = synth.FULL
+    U, n = 64, 8
+    embs = [synth.synth_embeds(2, 64, dims.hidden_size, 1000 + u) for u in range(U)]
+    path = synth.ensure_checkpoint(dims, 1234)
+    model = cb.load_t3(path, device=0)
+    try:
+        with cb.Session(model, embs, max_new_tokens=n, top_p=0.0, mask_stop=True) as s:
+            lg32 = s.logits()
+            s.decode(n)
+            outs = [s.tokens(u) for u in range(U)]
+        for u in (0, 17, 40, 63):
+            alone = cb.t3_inference(model, embs[u], max_new_tokens=n, top_p=0.0)
+            assert list(alone[:n]) == list(outs[u][: len(alone[:n])]), f"utterance {u}"
+    finally:
+        model.close()
+    model = cb.load_t3(path, device=0, dtype="bf16")
+    try:
+        with cb.Session(model, embs, max_new_tokens=n, top_p=0.0, mask_stop=True) as s:
+            lg16 = s.logits()
+            s.decode(n)
+            n16, _ = s.status()
+        assert int(n16.min()) == n
+        assert rel_err(lg16, lg32) < BF16_LOGIT_TOL
+    finally:
+        model.close()
