@@ -149,3 +149,25 @@ def test_turbo_full_size_logits_fp32_and_bf16():
                     assert list(s.tokens(0)) == ref.tokens
         finally:
             model.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", LOGIT_TOL), ("bf16", 3e-2)])
+def test_turbo_70_rows_128_row_gemm_tiles(dtype, tol):
+    """70 sentences, one row each (no CFG): the GPT-2 linears on the 128-row MFMA tiles -- LayerNorm rows, biases in
+    the epilogues, GELU, no RoPE; bf16: bf16 activation rows and KV cache.  Teacher-forced against the oracle."""
+    dims = synth.TURBO_TINY
+    om = turbo_oracle(dims, 4321)
+    model = _open(dims, 4321, dtype=dtype)
+    try:
+        U, n = 70, 4
+        embs = [synth.synth_embeds(1, 3 + (5 * u) % 19, dims.hidden_size, 700 + u) for u in range(U)]
+        refs = [O.t3_inference_turbo(om, e, O.TurboParams(max_new_tokens=n, top_p=0.0), mask_stop=True) for e in embs]
+        forced = np.array([r.tokens for r in refs])
+        with cb.Session(model, embs, max_new_tokens=n, top_p=0.0, mask_stop=True, forced=forced) as s:
+            for i in range(n + 1):
+                lg = s.logits()
+                for u in range(U):
+                    assert rel_err(lg[u:u + 1], refs[u].raw_logits[i]) < tol, f"{dtype} sentence {u} step {i}"
+                s.decode(1)
+    finally:
+        model.close()
