@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="weight storage type")
     ap.add_argument("--cpu-steps", type=int, default=600, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barriers (gloo: rehearsal of the N > 1 path on a box with fewer GPUs "
+                         "than ranks; ranks then share devices round-robin)")
     return ap.parse_args()
 
 
@@ -107,11 +110,16 @@ def main():
     n_gpus = args.gpus
     import torch
     dist = None
+    if args.backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group("gloo")
         dist = dist_mod
     else:
         torch.cuda.set_device(local_rank)
@@ -153,7 +161,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
     ntok, _ = sess.status()
