@@ -615,19 +615,11 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
             const int s = s0 + u;
             if (s < S) {   // block-uniform
                 const int ua = (u + 1) % kDA, uw = (u + 1) % kDW;
-                // tile of step s+1 -> the LDS buffer last read in step s-1; then refill the ring slots
-                if (s + 1 < S) {
-                    T* dst = tl + ((s + 1) & 1) * (kRows * LD) + soff;
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(dst + p * 32 * LD) = ra[ua][p];
-                    *reinterpret_cast<uint4*>(dst + 4 * 32 * LD) = rw[uw];
-                }
-                if (s + 1 + kDA < S) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) ra[ua][p] = *reinterpret_cast<const uint4*>(src[p] + (size_t)(s + 1 + kDA) * KC);
-                }
-                if (s + 1 + kDW < S) rw[uw] = *reinterpret_cast<const uint4*>(src[4] + (size_t)(s + 1 + kDW) * KC);
+#if defined(T3K_GEMM_EXP) && (T3K_GEMM_EXP == 1 || T3K_GEMM_EXP == 3)
+                if (false) {
+#else
                 if (live) {
+#endif
                     // lane (nl, g) reads the 64 bytes g of its row: piece j of them feeds MFMA (group) j of the step
                     const T* tb = tl + (s & 1) * (kRows * LD);
                     const T* ab = tb + (wave * 16 + nl) * LD + g * (4 * E);
@@ -656,6 +648,30 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
                         }
                     }
                 }
+                // after the step's MFMAs: tile of step s+1 -> the LDS buffer last read in step s-1, then refill the ring
+                // slots.  (Order within the step is immaterial: staging before or after the MFMAs measures the same.
+                // gemm_micro, gate_up at 128 rows, 8 steps: barriers + global loads alone 2.75 us; + staging writes 2.77;
+                // + fragment reads and MFMAs 4.30; all three 5.43 -- the LDS serves 136 KB per step and the reads and
+                // writes contend for it.)
+                // (T3K_GEMM_EXP: timing diagnostics for scripts/micro/gemm_micro only, results are wrong: 1 = no fragment
+                // reads / MFMAs, 2 = no LDS staging writes, 3 = neither: barriers and global loads alone)
+#if !defined(T3K_GEMM_EXP) || (T3K_GEMM_EXP != 2 && T3K_GEMM_EXP != 3)
+                if (s + 1 < S) {
+                    T* dst = tl + ((s + 1) & 1) * (kRows * LD) + soff;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(dst + p * 32 * LD) = ra[ua][p];
+                    *reinterpret_cast<uint4*>(dst + 4 * 32 * LD) = rw[uw];
+                }
+#else
+                if (s + 1 < S) {   // keep the loaded registers alive without the LDS traffic
+                    asm volatile("" ::"v"(ra[ua][0].x), "v"(ra[ua][1].x), "v"(ra[ua][2].x), "v"(ra[ua][3].x), "v"(rw[uw].x));
+                }
+#endif
+                if (s + 1 + kDA < S) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) ra[ua][p] = *reinterpret_cast<const uint4*>(src[p] + (size_t)(s + 1 + kDA) * KC);
+                }
+                if (s + 1 + kDW < S) rw[uw] = *reinterpret_cast<const uint4*>(src[4] + (size_t)(s + 1 + kDW) * KC);
                 __syncthreads();
             }
         }
