@@ -545,18 +545,20 @@ __device__ __forceinline__ int tile32_feature(int t, int r32, int N) {
     return 32 * t + r32;
 }
 
-template <int EPI, typename T>
+template <int EPI, typename T, bool ADIRECT>
 __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte piece: 8 (bf16) or 4 (fp32)
     constexpr int KC = 16 * E, LD = KC + E;  // 256-byte step rows, row stride 272 B: the 16 rows of a fragment read fall in distinct banks
-    constexpr int kRows = 160;             // 128 activation rows + 32 weight rows per step
+    // LDS rows per step: ADIRECT stages only the 32 weight rows (the activation fragments go global -> registers),
+    // otherwise 128 activation rows + 32 weight rows
+    constexpr int kARows = ADIRECT ? 0 : 128, kRows = kARows + 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char tl_raw[];
     T* tl = reinterpret_cast<T*>(tl_raw);   // [2][kRows][LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = lane & 15, g = lane >> 4;
     const int tile = blockIdx.x, m0 = blockIdx.y * 128, kz = blockIdx.z;
     const int K = a.K;
-    const int S = (K / KC) / (int)gridDim.z;   // 128-k steps of this block
+    const int S = (K / KC) / (int)gridDim.z;   // steps of this block
     unsigned long long* dbg = a.dbg != nullptr && tid == 0
                                   ? a.dbg + 4 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
     if (dbg) dbg[0] = wall_clock64();
@@ -564,17 +566,28 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     const T* Wp = static_cast<const T*>(a.W);
     const T* Ap = static_cast<const T*>(a.A);
 
-    // staging: a step's tile is 160 rows x 256 B; thread t moves the 16 B piece t & 15 of rows (t >> 4) + 32 p,
-    // p = 0..4, so 16 consecutive lanes fetch one whole 256-byte run (rows 0..127 activations, 128..159 weights).
-    // Fetching the activation rows straight into MFMA fragments instead (16 rows x 64 B per instruction) asks L2 for
-    // every line four times: measured 3-4x slower at 128 rows.
+    // staging: thread t moves the 16 B piece t & 15 of tile rows (t >> 4) + 32 p, so 16 consecutive lanes fetch one
+    // whole 256-byte run.  !ADIRECT: p = 0..3 activation rows, p = 4 the weight rows.
+    // ADIRECT: only the weight rows are staged; wave w reads the MFMA fragments of its 16 activation rows straight
+    // from global memory (L2): lane (n, g) takes the 16 bytes g of the 64-byte run j of its row for MFMA (group) j, so
+    // one load instruction covers 16 rows x one whole 64-byte segment and every segment is requested exactly once.
+    // (A first attempt gave lane (n, g) the 64 bytes g of the 256-byte run -- four 16-byte slivers of four different
+    // segments per instruction, every segment requested four times: 3-4x slower.)
     const int srow = tid >> 4, spiece = tid & 15;
     const T* src[5];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        int r = m0 + p * 32 + srow;
+    const bool live = m0 + wave * 16 < a.M;
+    if constexpr (ADIRECT) {
+        int r = m0 + wave * 16 + nl;
         r = r < a.M ? r : a.M - 1;
-        src[p] = Ap + (size_t)r * K + kbeg + spiece * E;
+        src[0] = Ap + (size_t)r * K + kbeg + g * E;   // + step * KC + j * 4E
+        src[1] = src[2] = src[3] = src[0];
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int r = m0 + p * 32 + srow;
+            r = r < a.M ? r : a.M - 1;
+            src[p] = Ap + (size_t)r * K + kbeg + spiece * E;
+        }
     }
     {
         int sf = tile32_feature<EPI>(tile, srow, a.N);
@@ -582,29 +595,33 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
         src[4] = Wp + (size_t)sf * K + kbeg + spiece * E;
     }
     const int soff = srow * LD + spiece * E;
-    const bool live = m0 + wave * 16 < a.M;
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     // register rings: the weights come from HBM (2-3 us under load) and are requested kDW steps ahead, which for the
     // decode shapes (K <= 1024 per block) is the block's whole weight slice at kernel start (default cache policy:
     // non-temporal weight loads measured 1-2 % slower here, gate_up 21.1 -> 21.7 us, down 11.3 -> 12.3); the activation rows come
-    // from L2 and run kDA steps ahead.  A step of MFMAs is only ~0.1-0.2 us.
+    // from L2 and run kDA steps ahead.
     constexpr int kDW = 8, kDA = 3;
     uint4 rw[kDW], ra[kDA][4];
+    auto load_a = [&](int step, int p) -> uint4 {   // piece p of the thread's activation data of a step
+        if constexpr (ADIRECT) return *reinterpret_cast<const uint4*>(src[0] + (size_t)step * KC + p * (4 * E));
+        else return *reinterpret_cast<const uint4*>(src[p] + (size_t)step * KC);
+    };
 #pragma unroll
     for (int q = 0; q < kDW; ++q) rw[q] = (q < S) ? *reinterpret_cast<const uint4*>(src[4] + (size_t)q * KC) : uint4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int q = 0; q < kDA; ++q)
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            ra[q][p] = (q < S) ? *reinterpret_cast<const uint4*>(src[p] + (size_t)q * KC) : uint4{0u, 0u, 0u, 0u};
+        for (int p = 0; p < 4; ++p) ra[q][p] = (q < S && (!ADIRECT || live)) ? load_a(q, p) : uint4{0u, 0u, 0u, 0u};
+    if constexpr (!ADIRECT) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(&tl[soff + p * 32 * LD]) = ra[0][p];
-    *reinterpret_cast<uint4*>(&tl[soff + 4 * 32 * LD]) = rw[0];
-    if (kDA < S) {
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(&tl[soff + p * 32 * LD]) = ra[0][p];
+        if (kDA < S) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) ra[0][p] = *reinterpret_cast<const uint4*>(src[p] + (size_t)kDA * KC);
+            for (int p = 0; p < 4; ++p) ra[0][p] = load_a(kDA, p);
+        }
     }
+    *reinterpret_cast<uint4*>(&tl[soff + kARows * LD]) = rw[0];
     if (kDW < S) rw[0] = *reinterpret_cast<const uint4*>(src[4] + (size_t)kDW * KC);
     __syncthreads();
     if (dbg) dbg[1] = wall_clock64();
@@ -614,29 +631,37 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
         for (int u = 0; u < 24; ++u) {
             const int s = s0 + u;
             if (s < S) {   // block-uniform
-                const int ua = (u + 1) % kDA, uw = (u + 1) % kDW;
+                // !ADIRECT: ring slot (s+1) % kDA holds the staging pieces of step s+1; ADIRECT: slot s % kDA holds the
+                // fragments of step s itself
+                const int ua = ADIRECT ? u % kDA : (u + 1) % kDA, uw = (u + 1) % kDW;
 #if defined(T3K_GEMM_EXP) && (T3K_GEMM_EXP == 1 || T3K_GEMM_EXP == 3)
                 if (false) {
 #else
                 if (live) {
 #endif
-                    // lane (nl, g) reads the 64 bytes g of its row: piece j of them feeds MFMA (group) j of the step
+                    // lane (nl, g) of the weight rows reads the 16 bytes g of run j (ADIRECT, as its activation fragment) or
+                    // piece j of the 64 bytes g (both operands from LDS): either way a fixed permutation of the dot product's
+                    // terms over the MFMA k slots, the same for both operands
                     const T* tb = tl + (s & 1) * (kRows * LD);
                     const T* ab = tb + (wave * 16 + nl) * LD + g * (4 * E);
-                    const T* wb = tb + (128 + nl) * LD + g * (4 * E);
+                    const T* wb = tb + (kARows + nl) * LD + (ADIRECT ? g * E : g * (4 * E));
+                    constexpr int jstride = ADIRECT ? 4 * E : E;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
+                        uint4 araw;
+                        if constexpr (ADIRECT) araw = ra[ua][j];
+                        else araw = *reinterpret_cast<const uint4*>(ab + j * E);
                         if constexpr (sizeof(T) == 2) {
-                            const bf16x8 av = *reinterpret_cast<const bf16x8*>(ab + j * 8);
-                            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wb + j * 8);
-                            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wb + 16 * LD + j * 8);
+                            const bf16x8 av = __builtin_bit_cast(bf16x8, araw);
+                            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wb + j * jstride);
+                            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wb + 16 * LD + j * jstride);
                             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0, acc0, 0, 0, 0);
                             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1, acc1, 0, 0, 0);
                         } else {
                             // fp32 operands: exact fp32 fma chains (v_mfma_f32_16x16x4_f32, one k per lane group)
-                            const float4 av = *reinterpret_cast<const float4*>(ab + j * 4);
-                            const float4 b0 = *reinterpret_cast<const float4*>(wb + j * 4);
-                            const float4 b1 = *reinterpret_cast<const float4*>(wb + 16 * LD + j * 4);
+                            const float4 av = __builtin_bit_cast(float4, araw);
+                            const float4 b0 = *reinterpret_cast<const float4*>(wb + j * jstride);
+                            const float4 b1 = *reinterpret_cast<const float4*>(wb + 16 * LD + j * jstride);
                             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc0, 0, 0, 0);
                             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc1, 0, 0, 0);
                             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc0, 0, 0, 0);
@@ -650,26 +675,35 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
                 }
                 // after the step's MFMAs: tile of step s+1 -> the LDS buffer last read in step s-1, then refill the ring
                 // slots.  (Order within the step is immaterial: staging before or after the MFMAs measures the same.
-                // gemm_micro, gate_up at 128 rows, 8 steps: barriers + global loads alone 2.75 us; + staging writes 2.77;
-                // + fragment reads and MFMAs 4.30; all three 5.43 -- the LDS serves 136 KB per step and the reads and
-                // writes contend for it.)
+                // gemm_micro, gate_up at 128 rows, 8 steps, !ADIRECT: barriers + global loads alone 2.75 us; + staging
+                // writes 2.77; + fragment reads and MFMAs 4.30; all three 5.43 -- the LDS serves 136 KB per step and the
+                // reads and writes contend for it.)
                 // (T3K_GEMM_EXP: timing diagnostics for scripts/micro/gemm_micro only, results are wrong: 1 = no fragment
                 // reads / MFMAs, 2 = no LDS staging writes, 3 = neither: barriers and global loads alone)
 #if !defined(T3K_GEMM_EXP) || (T3K_GEMM_EXP != 2 && T3K_GEMM_EXP != 3)
                 if (s + 1 < S) {
                     T* dst = tl + ((s + 1) & 1) * (kRows * LD) + soff;
+                    if constexpr (!ADIRECT) {
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(dst + p * 32 * LD) = ra[ua][p];
-                    *reinterpret_cast<uint4*>(dst + 4 * 32 * LD) = rw[uw];
+                        for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(dst + p * 32 * LD) = ra[ua][p];
+                    }
+                    *reinterpret_cast<uint4*>(dst + kARows * LD) = rw[uw];
                 }
 #else
                 if (s + 1 < S) {   // keep the loaded registers alive without the LDS traffic
                     asm volatile("" ::"v"(ra[ua][0].x), "v"(ra[ua][1].x), "v"(ra[ua][2].x), "v"(ra[ua][3].x), "v"(rw[uw].x));
                 }
 #endif
-                if (s + 1 + kDA < S) {
+                if constexpr (ADIRECT) {
+                    if (live && s + kDA < S) {
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) ra[ua][p] = *reinterpret_cast<const uint4*>(src[p] + (size_t)(s + 1 + kDA) * KC);
+                        for (int p = 0; p < 4; ++p) ra[ua][p] = load_a(s + kDA, p);
+                    }
+                } else {
+                    if (s + 1 + kDA < S) {
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) ra[ua][p] = load_a(s + 1 + kDA, p);
+                    }
                 }
                 if (s + 1 + kDW < S) rw[uw] = *reinterpret_cast<const uint4*>(src[4] + (size_t)(s + 1 + kDW) * KC);
                 __syncthreads();
@@ -767,8 +801,8 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(float* __restrict__ 
     y[o] = resid != nullptr ? __fadd_rn(r, v) : v;
 }
 
-template <int EPI, typename T>
-hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s) {
+template <int EPI, typename T, bool ADIRECT>
+hipError_t launch_gemm_rows_v(const GemmArgs& a, hipStream_t s) {
     constexpr int KC = 16 * (16 / (int)sizeof(T));   // the kernel's step: 128 (bf16) or 64 (fp32) k
     int tiles;
     if (EPI == EPI_ROPE_KV) tiles = (a.N / kHeadDim) * 2;
@@ -782,19 +816,19 @@ hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s) {
                (size_t)(2 * ks) * a.M * a.N <= a.part_floats)
             ks *= 2;
     }
-    constexpr int lds = 2 * 160 * (128 + 8) * 2;   // 87,040 B: two step tiles
+    constexpr int lds = 2 * (ADIRECT ? 32 : 160) * (128 + 8) * 2;   // two step tiles: 87,040 B, or 17,408 B (weights only)
     // the attribute belongs to the (kernel, device) pair: one flag per EPI instantiation and device
     static bool attr_done[64] = {};   // (static in a function template: one array per <EPI, T>)
     int dev = 0;
     hipError_t ed = hipGetDevice(&dev);
     if (ed != hipSuccess) return ed;
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T>),
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, ADIRECT>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e0 != hipSuccess) return e0;
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_rows_kernel<EPI, T>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, ADIRECT>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     hipError_t e = hipGetLastError();
     if (a.ks_out != nullptr) *a.ks_out = ks;
     if (e != hipSuccess || ks == 1) return e;
@@ -802,6 +836,17 @@ hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(fold_partials_kernel, dim3(a.M, (a.N + 255) / 256), dim3(256), 0, s, a.y, EPI == EPI_RESID ? a.resid : nullptr, a.part, ks,
                        a.bias, a.M, a.N, a.ldy);
     return hipGetLastError();
+}
+
+template <int EPI, typename T>
+hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s) {
+    // T3MI_GEMM_ADIRECT=1: activation fragments straight from global memory, only the weights through LDS (17 KB of
+    // LDS and 72 KB of LDS traffic per step instead of 87 KB and 136 KB).  Parity-green but SLOWER at 128 rows
+    // (gemm_micro: gate_up 13.9 vs 12.0 us, first tile 5.4 vs 3.6 us, loop 6.0 vs 5.4 us; batch-64 step 2.88 vs
+    // 2.68 ms): 16 rows x 64 B per load instruction costs the vector-memory pipe more than whole 256-byte runs cost
+    // the LDS.  Kept selectable for A/B measurements.
+    static const bool adirect = [] { const char* v = getenv("T3MI_GEMM_ADIRECT"); return v && v[0] == '1'; }();
+    return adirect ? launch_gemm_rows_v<EPI, T, true>(a, s) : launch_gemm_rows_v<EPI, T, false>(a, s);
 }
 
 template <typename G, int MT, int KS, int EPI>
