@@ -306,31 +306,37 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(float* __restrict__
                                                              const float* __restrict__ b, float eps, AT* __restrict__ out, int d,
                                                              const float* __restrict__ part, int ks, const float* __restrict__ pbias,
                                                              int M) {
+    // same 16-byte access shape as rmsnorm_rows_kernel: thread t owns elements 4t..4t+3 of each 1024-element slice
+    constexpr int kV = kNormMaxPer / 4;
     __shared__ float sred[8];
     const int m = blockIdx.x, tid = threadIdx.x;
     float* xr = x + (size_t)m * d;
-    float v[kNormMaxPer];
+    float4 v[kV];
     float sm = 0.f;
 #pragma unroll
-    for (int j = 0; j < kNormMaxPer; ++j) {
-        const int i = tid + j * 256;
-        v[j] = 0.f;
+    for (int j = 0; j < kV; ++j) {
+        const int i = 4 * tid + j * 1024;
+        v[j] = float4{0.f, 0.f, 0.f, 0.f};
         if (i < d) {
-            float t = xr[i];
+            float4 t = *reinterpret_cast<const float4*>(xr + i);
             if (ks > 0) {
-                float pp[8];   // all partials requested at once, then added in order
+                float4 pp[8];   // all partials requested at once, then added in order
 #pragma unroll
-                for (int s2 = 0; s2 < 8; ++s2) pp[s2] = s2 < ks ? part[((size_t)s2 * M + m) * d + i] : 0.f;
-                float p = pp[0];
+                for (int s2 = 0; s2 < 8; ++s2)
+                    pp[s2] = s2 < ks ? *reinterpret_cast<const float4*>(part + ((size_t)s2 * M + m) * d + i) : float4{0.f, 0.f, 0.f, 0.f};
+                float4 p = pp[0];
 #pragma unroll
                 for (int s2 = 1; s2 < 8; ++s2)
-                    if (s2 < ks) p += pp[s2];
-                if (pbias != nullptr) p = __fadd_rn(p, pbias[i]);
-                t = __fadd_rn(t, p);
-                xr[i] = t;
+                    if (s2 < ks) { p.x += pp[s2].x; p.y += pp[s2].y; p.z += pp[s2].z; p.w += pp[s2].w; }
+                if (pbias != nullptr) {
+                    const float4 bb = *reinterpret_cast<const float4*>(pbias + i);
+                    p.x = __fadd_rn(p.x, bb.x); p.y = __fadd_rn(p.y, bb.y); p.z = __fadd_rn(p.z, bb.z); p.w = __fadd_rn(p.w, bb.w);
+                }
+                t.x = __fadd_rn(t.x, p.x); t.y = __fadd_rn(t.y, p.y); t.z = __fadd_rn(t.z, p.z); t.w = __fadd_rn(t.w, p.w);
+                *reinterpret_cast<float4*>(xr + i) = t;
             }
             v[j] = t;
-            sm += t;
+            sm += (t.x + t.y) + (t.z + t.w);
         }
     }
 #pragma unroll
@@ -340,11 +346,11 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(float* __restrict__
     const float mean = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / (float)d;
     float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < kNormMaxPer; ++j) {
-        const int i = tid + j * 256;
+    for (int j = 0; j < kV; ++j) {
+        const int i = 4 * tid + j * 1024;
         if (i < d) {
-            const float c = v[j] - mean;
-            ss = fmaf(c, c, ss);
+            const float c0 = v[j].x - mean, c1 = v[j].y - mean, c2 = v[j].z - mean, c3 = v[j].w - mean;
+            ss = fmaf(c0, c0, ss); ss = fmaf(c1, c1, ss); ss = fmaf(c2, c2, ss); ss = fmaf(c3, c3, ss);
         }
     }
 #pragma unroll
@@ -354,9 +360,22 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(float* __restrict__
     const float var = ((sred[4] + sred[5]) + (sred[6] + sred[7])) / (float)d;
     const float rs = 1.0f / sqrtf(var + eps);
 #pragma unroll
-    for (int j = 0; j < kNormMaxPer; ++j) {
-        const int i = tid + j * 256;
-        if (i < d) Act<AT>::store(out + (size_t)m * d + i, __fadd_rn(__fmul_rn(__fmul_rn(v[j] - mean, rs), w[i]), b[i]));
+    for (int j = 0; j < kV; ++j) {
+        const int i = 4 * tid + j * 1024;
+        if (i < d) {
+            const float4 ww = *reinterpret_cast<const float4*>(w + i), bb = *reinterpret_cast<const float4*>(b + i);
+            AT* o = out + (size_t)m * d + i;
+            const float y0 = __fadd_rn(__fmul_rn(__fmul_rn(v[j].x - mean, rs), ww.x), bb.x);
+            const float y1 = __fadd_rn(__fmul_rn(__fmul_rn(v[j].y - mean, rs), ww.y), bb.y);
+            const float y2 = __fadd_rn(__fmul_rn(__fmul_rn(v[j].z - mean, rs), ww.z), bb.z);
+            const float y3 = __fadd_rn(__fmul_rn(__fmul_rn(v[j].w - mean, rs), ww.w), bb.w);
+            if constexpr (sizeof(AT) == 2) {
+                *reinterpret_cast<uint2*>(o) = uint2{(uint32_t)f2bf(y0) | ((uint32_t)f2bf(y1) << 16),
+                                                     (uint32_t)f2bf(y2) | ((uint32_t)f2bf(y3) << 16)};
+            } else {
+                *reinterpret_cast<float4*>(o) = float4{y0, y1, y2, y3};
+            }
+        }
     }
 }
 
@@ -966,7 +985,7 @@ hipError_t launch_rmsnorm_rows(float* x, const float* w, float eps, void* out, i
 
 hipError_t launch_layernorm_rows(float* x, const float* w, const float* b, float eps, void* out, int M, int d, int act_bf16,
                                  hipStream_t s, const float* part, int ks, const float* pbias) {
-    if (!x || !w || !b || !out || M <= 0 || d <= 0 || d > 256 * kNormMaxPer || (ks > 0 && !part)) return hipErrorInvalidValue;
+    if (!x || !w || !b || !out || M <= 0 || d <= 0 || d > 256 * kNormMaxPer || (d & 3) || (ks > 0 && !part)) return hipErrorInvalidValue;
     if (act_bf16)
         hipLaunchKernelGGL(layernorm_rows_kernel<uint16_t>, dim3(M), dim3(256), 0, s, x, w, b, eps, static_cast<uint16_t*>(out), d,
                            part, ks, pbias, M);
