@@ -16,6 +16,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 namespace t3k {
 
@@ -582,6 +583,76 @@ __device__ __forceinline__ int tile32_feature(int t, int r32, int N) {
     return 32 * t + r32;
 }
 
+// Epilogue of one output row mi for the PAIR of partner features that column nl of a 32-feature tile holds
+// (v0: sub-tile 0, v1: sub-tile 1; tile32_feature gives their feature ids).  Shared by gemm_rows_kernel and
+// gemm_wide_kernel.
+template <int EPI, typename T>
+__device__ __forceinline__ void rows_epilogue(const GemmArgs& a, int tile, int nl, int mi, float v0, float v1, int kz, bool ksplit) {
+    if (mi >= a.M) return;
+    const int f0 = tile32_feature<EPI>(tile, nl, a.N), f1 = tile32_feature<EPI>(tile, 16 + nl, a.N);
+    if (EPI == EPI_STORE || EPI == EPI_RESID) {
+        if (ksplit) {   // K split over blocks: fp32 partial slab of this K range
+            float* pr = a.part + ((size_t)kz * a.M + mi) * a.N;
+            if (f0 < a.N) pr[f0] = v0;
+            if (f1 < a.N) pr[f1] = v1;
+        } else {
+            const size_t o = (size_t)mi * a.ldy;
+            if (f0 < a.N) {
+                if (a.bias != nullptr) v0 = __fadd_rn(v0, a.bias[f0]);
+                a.y[o + f0] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o + f0], v0) : v0;
+            }
+            if (f1 < a.N) {
+                if (a.bias != nullptr) v1 = __fadd_rn(v1, a.bias[f1]);
+                a.y[o + f1] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o + f1], v1) : v1;
+            }
+        }
+    } else if (EPI == EPI_GELU) {   // gelu_tanh(c_fc(x) + b)  (R/t3.R:1303-1304)
+        T* yo = static_cast<T*>(a.yact) + (size_t)mi * a.N;
+        if (a.bias != nullptr) {
+            if (f0 < a.N) v0 = __fadd_rn(v0, a.bias[f0]);
+            if (f1 < a.N) v1 = __fadd_rn(v1, a.bias[f1]);
+        }
+        const float i0 = 0.7978845608028654f * (v0 + 0.044715f * v0 * v0 * v0);
+        const float i1 = 0.7978845608028654f * (v1 + 0.044715f * v1 * v1 * v1);
+        if (f0 < a.N) Act<T>::store(yo + f0, 0.5f * v0 * (1.0f + tanhf(i0)));
+        if (f1 < a.N) Act<T>::store(yo + f1, 0.5f * v1 * (1.0f + tanhf(i1)));
+    } else if (EPI == EPI_SWIGLU) {   // silu(gate) * up  (R/llama.R:302, 307)
+        const float sg = 1.0f / (1.0f + expf(-v0));
+        Act<T>::store(static_cast<T*>(a.yact) + (size_t)mi * (a.N >> 1) + 16 * tile + nl, __fmul_rn(__fmul_rn(v0, sg), v1));
+    } else {  // EPI_ROPE_KV
+        const int pos = a.posmap[mi];
+        if (pos < 0) return;
+        const int H = a.n_heads, hm = tile >> 1, i = ((tile & 1) << 4) + nl;
+        const int kind = hm / H, head = hm % H;
+        float lo = v0, hi = v1;
+        if (a.bias != nullptr) {
+            lo = __fadd_rn(lo, a.bias[hm * kHeadDim + i]);
+            hi = __fadd_rn(hi, a.bias[hm * kHeadDim + i + 32]);
+        }
+        if (kind < 2 && a.rope) {
+            const float cs = a.rope_cos[(size_t)pos * kHeadDim + i];
+            const float sn = a.rope_sin[(size_t)pos * kHeadDim + i];
+            const float nlo = __fadd_rn(__fmul_rn(lo, cs), __fmul_rn(-hi, sn));
+            const float nhi = __fadd_rn(__fmul_rn(hi, cs), __fmul_rn(lo, sn));
+            lo = nlo; hi = nhi;
+        }
+        if (kind == 0) {
+            float* q = a.q + (size_t)mi * (H * kHeadDim) + head * kHeadDim;
+            q[i] = lo; q[i + 32] = hi;
+        } else {
+            const int crow = a.rowmap ? a.rowmap[mi] : mi;
+            const size_t co = (((size_t)crow * H + head) * a.max_len + pos) * kHeadDim;
+            if (a.kv_bf16) {
+                uint16_t* cb = static_cast<uint16_t*>(kind == 1 ? a.kcache : a.vcache) + co;
+                cb[i] = f2bf(lo); cb[i + 32] = f2bf(hi);
+            } else {
+                float* cb = static_cast<float*>(kind == 1 ? a.kcache : a.vcache) + co;
+                cb[i] = lo; cb[i + 32] = hi;
+            }
+        }
+    }
+}
+
 template <int EPI, typename T, bool ADIRECT>
 __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte piece: 8 (bf16) or 4 (fp32)
@@ -750,72 +821,167 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     if (dbg) dbg[2] = wall_clock64();
     if (!live) return;
     // accumulator layout: row = g*4 + r of the wave's 16 rows, column nl of the sub-tile
-    const int f0 = tile32_feature<EPI>(tile, nl, a.N), f1 = tile32_feature<EPI>(tile, 16 + nl, a.N);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int mi = m0 + wave * 16 + g * 4 + r;
-        if (mi >= a.M) continue;
-        float v0 = acc0[r], v1 = acc1[r];
-        if (EPI == EPI_STORE || EPI == EPI_RESID) {
-            if (gridDim.z > 1) {   // K split over blocks: fp32 partial slab of this K range
-                float* pr = a.part + ((size_t)kz * a.M + mi) * a.N;
-                if (f0 < a.N) pr[f0] = v0;
-                if (f1 < a.N) pr[f1] = v1;
-            } else {
-                const size_t o = (size_t)mi * a.ldy;
-                if (f0 < a.N) {
-                    if (a.bias != nullptr) v0 = __fadd_rn(v0, a.bias[f0]);
-                    a.y[o + f0] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o + f0], v0) : v0;
-                }
-                if (f1 < a.N) {
-                    if (a.bias != nullptr) v1 = __fadd_rn(v1, a.bias[f1]);
-                    a.y[o + f1] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o + f1], v1) : v1;
-                }
-            }
-        } else if (EPI == EPI_GELU) {   // gelu_tanh(c_fc(x) + b)  (R/t3.R:1303-1304)
-            T* yo = static_cast<T*>(a.yact) + (size_t)mi * a.N;
-            if (a.bias != nullptr) { v0 = __fadd_rn(v0, a.bias[f0]); v1 = __fadd_rn(v1, a.bias[f1]); }
-            const float i0 = 0.7978845608028654f * (v0 + 0.044715f * v0 * v0 * v0);
-            const float i1 = 0.7978845608028654f * (v1 + 0.044715f * v1 * v1 * v1);
-            if (f0 < a.N) Act<T>::store(yo + f0, 0.5f * v0 * (1.0f + tanhf(i0)));
-            if (f1 < a.N) Act<T>::store(yo + f1, 0.5f * v1 * (1.0f + tanhf(i1)));
-        } else if (EPI == EPI_SWIGLU) {   // silu(gate) * up  (R/llama.R:302, 307)
-            const float sg = 1.0f / (1.0f + expf(-v0));
-            Act<T>::store(static_cast<T*>(a.yact) + (size_t)mi * (a.N >> 1) + 16 * tile + nl, __fmul_rn(__fmul_rn(v0, sg), v1));
-        } else {  // EPI_ROPE_KV
-            const int pos = a.posmap[mi];
-            if (pos < 0) continue;
-            const int H = a.n_heads, hm = tile >> 1, i = ((tile & 1) << 4) + nl;
-            const int kind = hm / H, head = hm % H;
-            float lo = v0, hi = v1;
-            if (a.bias != nullptr) {
-                lo = __fadd_rn(lo, a.bias[hm * kHeadDim + i]);
-                hi = __fadd_rn(hi, a.bias[hm * kHeadDim + i + 32]);
-            }
-            if (kind < 2 && a.rope) {
-                const float cs = a.rope_cos[(size_t)pos * kHeadDim + i];
-                const float sn = a.rope_sin[(size_t)pos * kHeadDim + i];
-                const float nlo = __fadd_rn(__fmul_rn(lo, cs), __fmul_rn(-hi, sn));
-                const float nhi = __fadd_rn(__fmul_rn(hi, cs), __fmul_rn(lo, sn));
-                lo = nlo; hi = nhi;
-            }
-            if (kind == 0) {
-                float* q = a.q + (size_t)mi * (H * kHeadDim) + head * kHeadDim;
-                q[i] = lo; q[i + 32] = hi;
-            } else {
-                const int crow = a.rowmap ? a.rowmap[mi] : mi;
-                const size_t co = (((size_t)crow * H + head) * a.max_len + pos) * kHeadDim;
-                if (a.kv_bf16) {
-                    uint16_t* cb = static_cast<uint16_t*>(kind == 1 ? a.kcache : a.vcache) + co;
-                    cb[i] = f2bf(lo); cb[i + 32] = f2bf(hi);
-                } else {
-                    float* cb = static_cast<float*>(kind == 1 ? a.kcache : a.vcache) + co;
-                    cb[i] = lo; cb[i + 32] = hi;
-                }
+    for (int r = 0; r < 4; ++r)
+        rows_epilogue<EPI, T>(a, tile, nl, m0 + wave * 16 + g * 4 + r, acc0[r], acc1[r], kz, gridDim.z > 1);
+    if (dbg) dbg[3] = wall_clock64();
+}
+
+// ---- bf16 GEMM for more than 128 rows (512 utterances per GPU, the prompt prefill of a batch) --------------------
+// With many rows the linears are real GEMMs (1 TFLOP per decode step at 1024 rows) and gemm_rows_kernel's 16 x 32
+// wave tile is LDS-bound at ~8 % of the MFMA peak (136 KB of LDS traffic per 0.5 M multiply-adds).  Here a block of
+// 8 waves owns 64*MT rows x 32*NT features: waves sit 4 (rows) x 2 (features), a wave holds MT x NT accumulator
+// tiles of 16 x 16 (MT = NT = 4: 64 rows x 64 features, 64 accumulator registers), so per 64-k step the block
+// writes (64 MT + 32 NT) x 128 B to LDS and its waves read 8 x (16 MT + 16 NT) x 128 B: 176 KB per 2.1 M
+// multiply-adds at MT = NT = 4, a third of the traffic per product.  A step's rows are 128 B (8 lanes fetch one
+// run), row stride 144 B (16-row fragment reads hit 16 distinct bank groups); register rings keep kWA steps of
+// activations (L2) and kWW steps of weights (HBM / MALL) in flight; two LDS buffers, one barrier per step.
+// Feature tiles keep the partner layout of tile32_feature, so the epilogues are those of gemm_rows_kernel.
+// Blocks that share a weight tile (the row chunks) are placed on the same XCD: linear block id -> XCD id % 8, and
+// within an XCD the row chunk runs fastest.  K may be split over blockIdx.y for the residual GEMMs (fp32 partial
+// slabs, folded in a fixed order by the next row norm or fold_partials_kernel).
+template <int EPI, int MT, int NT>
+__global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a, int tiles32, int chunks, int nblk) {
+    using T = uint16_t;
+    constexpr int BM = 64 * MT, BN = 32 * NT, LD = 72;   // LDS row stride in elements: 128 B of data + 16 B
+    constexpr int kRows = BM + BN;
+    constexpr int PW = BN / 64;                          // weight pieces per thread and step (A pieces: MT)
+    static_assert(NT == 2 || NT == 4, "feature groups of 64 or 128");
+    extern __shared__ __attribute__((aligned(16))) unsigned char tlw_raw[];
+    T* tl = reinterpret_cast<T*>(tlw_raw);               // [2][kRows][LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware placement: consecutive linear ids go round the 8 XCDs; slot = position inside the XCD's sequence
+    const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+    const int blk = (slot / chunks) * 8 + xcd, chunk = slot % chunks;
+    if (blk >= nblk) return;                             // block-uniform
+    const int m0 = chunk * BM, kz = blockIdx.y;
+    const int K = a.K;
+    const int S = (K / 64) / (int)gridDim.y;             // 64-k steps of this block
+    const int kbeg = kz * S * 64;
+    const T* Wp = static_cast<const T*>(a.W);
+    const T* Ap = static_cast<const T*>(a.A);
+
+    const int srow = tid >> 3, spiece = tid & 7;         // staging: 8 lanes per 128-byte run, rows srow + 64 p
+    const T* srcA[MT];
+    const T* srcW[PW];
+#pragma unroll
+    for (int p = 0; p < MT; ++p) {
+        int r = m0 + p * 64 + srow;
+        r = r < a.M ? r : a.M - 1;
+        srcA[p] = Ap + (size_t)r * K + kbeg + spiece * 8;
+    }
+#pragma unroll
+    for (int p = 0; p < PW; ++p) {
+        const int wr = p * 64 + srow;                    // weight row of the block: 32-feature tile wr / 32, row wr % 32
+        int t = blk * NT + (wr >> 5);
+        t = t < tiles32 ? t : tiles32 - 1;
+        int f = tile32_feature<EPI>(t, wr & 31, a.N);
+        f = f < a.N ? f : a.N - 1;
+        srcW[p] = Wp + (size_t)f * K + kbeg + spiece * 8;
+    }
+    const int soff = srow * LD + spiece * 8;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int kWA = 2, kWW = 4;                      // ring depths (steps); the unrolled body covers lcm = 4 steps
+    uint4 ra[kWA][MT], rw[kWW][PW];
+#pragma unroll
+    for (int q = 0; q < kWW; ++q)
+#pragma unroll
+        for (int p = 0; p < PW; ++p) rw[q][p] = q < S ? *reinterpret_cast<const uint4*>(srcW[p] + (size_t)q * 64) : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < kWA; ++q)
+#pragma unroll
+        for (int p = 0; p < MT; ++p) ra[q][p] = q < S ? *reinterpret_cast<const uint4*>(srcA[p] + (size_t)q * 64) : uint4{0u, 0u, 0u, 0u};
+    // step 0 -> LDS buffer 0, refill ring slot 0
+#pragma unroll
+    for (int p = 0; p < MT; ++p) *reinterpret_cast<uint4*>(&tl[soff + p * 64 * LD]) = ra[0][p];
+#pragma unroll
+    for (int p = 0; p < PW; ++p) *reinterpret_cast<uint4*>(&tl[soff + (BM + p * 64) * LD]) = rw[0][p];
+    if (kWA < S) {
+#pragma unroll
+        for (int p = 0; p < MT; ++p) ra[0][p] = *reinterpret_cast<const uint4*>(srcA[p] + (size_t)kWA * 64);
+    }
+    if (kWW < S) {
+#pragma unroll
+        for (int p = 0; p < PW; ++p) rw[0][p] = *reinterpret_cast<const uint4*>(srcW[p] + (size_t)kWW * 64);
+    }
+    __syncthreads();
+    // One step.  U = s % 4 comes as a type so that the ring slots are literal indices (the rings stay in registers).
+    // CK = false is the steady state: no branches at all -- the tile of step s + 1 is always staged (after the last
+    // step it lands in a buffer nobody reads) and the refill loads clamp their step to S - 1 -- so that the compiler
+    // counts the outstanding loads exactly (with the conditional form every step waited for vmcnt(0): 2.5 us per step
+    // instead of 0.6).  CK = true keeps the conditions and serves the S % 4 tail.
+    auto step = [&](auto UC, auto CKC, int s) {
+        constexpr int u = decltype(UC)::value;
+        constexpr bool CK = decltype(CKC)::value;
+        if (CK && s >= S) return;   // block-uniform
+        constexpr int ua = (u + 1) % kWA, uw = (u + 1) % kWW;   // ring slots holding step s + 1
+        const T* tb = tl + (s & 1) * (kRows * LD);
+        // lane (nl, g), MFMA j of the step: the 16 bytes (4 j + g) of its row, k = 32 j + 8 g .. + 7
+        const T* ab = tb + (wm * (16 * MT) + nl) * LD + g * 8;
+        const T* wb = tb + (BM + wn * (16 * NT) + nl) * LD + g * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf16x8 af[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ab + i * 16 * LD + j * 32);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(wb + n * 16 * LD + j * 32);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][n], 0, 0, 0);
             }
         }
+        if (!CK || s + 1 < S) {   // step s + 1 -> the buffer last read in step s - 1
+            T* dst = tl + ((s + 1) & 1) * (kRows * LD) + soff;
+#pragma unroll
+            for (int p = 0; p < MT; ++p) *reinterpret_cast<uint4*>(dst + p * 64 * LD) = ra[ua][p];
+#pragma unroll
+            for (int p = 0; p < PW; ++p) *reinterpret_cast<uint4*>(dst + (BM + p * 64) * LD) = rw[uw][p];
+        }
+        if (!CK || s + 1 + kWA < S) {
+            const int sa = CK ? s + 1 + kWA : min(s + 1 + kWA, S - 1);
+#pragma unroll
+            for (int p = 0; p < MT; ++p) ra[ua][p] = *reinterpret_cast<const uint4*>(srcA[p] + (size_t)sa * 64);
+        }
+        if (!CK || s + 1 + kWW < S) {
+            const int sw = CK ? s + 1 + kWW : min(s + 1 + kWW, S - 1);
+#pragma unroll
+            for (int p = 0; p < PW; ++p) rw[uw][p] = *reinterpret_cast<const uint4*>(srcW[p] + (size_t)sw * 64);
+        }
+        __syncthreads();
+    };
+    using std::integral_constant;
+    int s0 = 0;
+    for (; s0 + 4 <= S; s0 += 4) {
+        step(integral_constant<int, 0>{}, std::false_type{}, s0);
+        step(integral_constant<int, 1>{}, std::false_type{}, s0 + 1);
+        step(integral_constant<int, 2>{}, std::false_type{}, s0 + 2);
+        step(integral_constant<int, 3>{}, std::false_type{}, s0 + 3);
     }
-    if (dbg) dbg[3] = wall_clock64();
+    step(integral_constant<int, 0>{}, std::true_type{}, s0);
+    step(integral_constant<int, 1>{}, std::true_type{}, s0 + 1);
+    step(integral_constant<int, 2>{}, std::true_type{}, s0 + 2);
+    // wave (wm, wn): rows m0 + 16 (MT wm + i) + 4 g + r; sub-tiles 2 tt / 2 tt + 1 are the partner halves of 32-feature
+    // tile blk NT + wn NT/2 + tt
+#pragma unroll
+    for (int tt = 0; tt < NT / 2; ++tt) {
+        const int t = blk * NT + wn * (NT / 2) + tt;
+        if (t >= tiles32) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                rows_epilogue<EPI, T>(a, t, nl, m0 + (wm * MT + i) * 16 + g * 4 + r, acc[i][2 * tt][r], acc[i][2 * tt + 1][r], kz,
+                                      gridDim.y > 1);
+    }
 }
 
 // y[m][i] = resid[m][i] + bias[i] + sum_s part[s][m][i], s ascending (the K-split of gemm_rows_kernel).
@@ -886,6 +1052,51 @@ hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s) {
     return adirect ? launch_gemm_rows_v<EPI, T, true>(a, s) : launch_gemm_rows_v<EPI, T, false>(a, s);
 }
 
+template <int EPI, int MT, int NT>
+hipError_t launch_gemm_wide_v(const GemmArgs& a, int tiles32, hipStream_t s) {
+    const int nblk = (tiles32 + NT - 1) / NT, chunks = (a.M + 64 * MT - 1) / (64 * MT);
+    int ks = 1;
+    if ((EPI == EPI_RESID || EPI == EPI_STORE) && a.part != nullptr) {
+        // few blocks: split K until the launch has ~192 (at least two 64-k steps per block)
+        while (ks < 8 && (long long)nblk * chunks * ks < 192 && (a.K / 64) % (2 * ks) == 0 && a.K / 64 / (2 * ks) >= 2 &&
+               (size_t)(2 * ks) * a.M * a.N <= a.part_floats)
+            ks *= 2;
+    }
+    constexpr int lds = 2 * (64 * MT + 32 * NT) * 144;   // two step tiles: 110,592 B at MT = NT = 4
+    static bool attr_done[64] = {};   // one flag per instantiation and device
+    int dev = 0;
+    hipError_t ed = hipGetDevice(&dev);
+    if (ed != hipSuccess) return ed;
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<EPI, MT, NT>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e0 != hipSuccess) return e0;
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    const int grid_x = 8 * ((nblk + 7) / 8) * chunks;
+    hipLaunchKernelGGL((gemm_wide_kernel<EPI, MT, NT>), dim3(grid_x, ks), dim3(512), lds, s, a, tiles32, chunks, nblk);
+    hipError_t e = hipGetLastError();
+    if (a.ks_out != nullptr) *a.ks_out = ks;
+    if (e != hipSuccess || ks == 1) return e;
+    if (a.ks_out != nullptr && EPI == EPI_RESID && a.resid == a.y) return e;   // the caller folds (fused into its norm launch)
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(a.M, (a.N + 255) / 256), dim3(256), 0, s, a.y, EPI == EPI_RESID ? a.resid : nullptr, a.part, ks,
+                       a.bias, a.M, a.N, a.ldy);
+    return hipGetLastError();
+}
+
+// block shape by the number of blocks it leaves: 256 x 128, 256 x 64, 128 x 64 (rows x features)
+template <int EPI>
+hipError_t launch_gemm_wide(const GemmArgs& a, hipStream_t s) {
+    int tiles32;
+    if (EPI == EPI_ROPE_KV) tiles32 = (a.N / kHeadDim) * 2;
+    else if (EPI == EPI_SWIGLU) tiles32 = a.N / 32;
+    else tiles32 = (a.N + 31) / 32;
+    const long long c4 = (a.M + 255) / 256;
+    if (((tiles32 + 3) / 4) * c4 >= 128) return launch_gemm_wide_v<EPI, 4, 4>(a, tiles32, s);
+    if (((tiles32 + 1) / 2) * c4 >= 128) return launch_gemm_wide_v<EPI, 4, 2>(a, tiles32, s);
+    return launch_gemm_wide_v<EPI, 2, 2>(a, tiles32, s);
+}
+
 template <typename G, int MT, int KS, int EPI>
 hipError_t launch_gemm_k(const GemmArgs& a, int tiles, hipStream_t s) {
     const int chunks = (a.M + MT * 16 - 1) / (MT * 16);
@@ -948,6 +1159,17 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
     // fp32 operands take it from 64 rows up: its block is 128 rows x 32 features whatever M is, and the exact-fp32 MFMA is
     // 16x slower than the bf16 one, so with few rows (one live wave per block) the first generation's 16-feature tiles
     // with K split over the waves win (8 rows, Turbo batched: 5156 vs 3516 tok/s)
+    // more than T3MI_GEMM_WIDE_MIN - 1 rows of bf16 operands: the register-blocked kernel (gemm_wide_kernel)
+    static const int wide_min = [] { const char* v = getenv("T3MI_GEMM_WIDE_MIN"); return v ? atoi(v) : 256; }();
+    if (wdtype == 1 && !gen1 && wide_min > 0 && a.M >= wide_min && a.K % 128 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0)) {
+        switch (epilogue) {
+            case EPI_STORE: return launch_gemm_wide<EPI_STORE>(a, s);
+            case EPI_RESID: return launch_gemm_wide<EPI_RESID>(a, s);
+            case EPI_GELU: return launch_gemm_wide<EPI_GELU>(a, s);
+            case EPI_SWIGLU: return launch_gemm_wide<EPI_SWIGLU>(a, s);
+            case EPI_ROPE_KV: return launch_gemm_wide<EPI_ROPE_KV>(a, s);
+        }
+    }
     if ((wdtype == 1 || (wdtype == 0 && a.M >= 64)) && !gen1 && a.K % 256 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0)) {
         if (wdtype == 1) {
             switch (epilogue) {

@@ -226,6 +226,34 @@ def t3_inference_cpp(model: T3Model, cond, text_tokens=None, max_new_tokens: int
     return toks
 
 
+def t3_inference_traced(model: T3Model, cond, text_tokens=None, max_new_tokens: int = 1000, temperature: float = 0.8,
+                        cfg_weight: float = 0.5, top_p: float = 0.95, min_p: float = 0.05,
+                        repetition_penalty: float = 1.2, max_cache_len: int = 350, seed: int = 0) -> np.ndarray:
+    """R/t3.R:685-871 (`traced = TRUE`): the arithmetic and sampling rule of t3_inference on a fixed
+    cache of `max_cache_len` slots; generation is limited to `max_cache_len - cond_len - 1` tokens
+    (R/t3.R:753) without a warning, and the stop token stays in the result.  There is nothing to
+    trace here (the decode step is a replayed HIP graph either way); the function exists so that
+    `generate(traced = TRUE)` callers keep their semantics."""
+    import warnings
+    p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
+                _lib.SAMPLER_R, max_cache_len, seed)
+    if isinstance(cond, T3Cond):
+        if text_tokens is None:
+            raise ValueError("t3_inference_traced(model, cond, text_tokens): text_tokens missing")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return _generate_tokens(model, [cond], [text_tokens], p, int(max_new_tokens))[0]
+    if text_tokens is not None:
+        raise ValueError("t3_inference_traced(model, embeds): text_tokens only goes with a T3Cond")
+    e = _as_embeds(model, cond, cfg_weight)
+    out = np.zeros(int(max_new_tokens), dtype=np.int32)
+    n = C.c_int32(0)
+    _lib.check(model._lib.t3mi_generate(
+        model._h, e.ctypes.data_as(C.POINTER(C.c_float)), e.shape[0], e.shape[1], C.byref(p),
+        out.ctypes.data_as(C.POINTER(C.c_int32)), out.shape[0], C.byref(n)))
+    return out[: n.value].astype(np.int64)
+
+
 def t3_inference_batch(model: T3Model, embeds_list: Sequence, text_tokens_list: Optional[Sequence] = None,
                        max_new_tokens: int = 1000,
                        temperature: float = 0.8, cfg_weight: float = 0.5, top_p: float = 0.95,

@@ -96,6 +96,24 @@ t3_inference_cpp <- function (model, cond, text_tokens, max_new_tokens = 1000,
     else torch::torch_tensor(integer(0), device = r$device)
 }
 
+#' Same signature and return value as t3_inference_traced (R/t3.R:685-688, 863-870): the R sampling rule on a
+#' cache of max_cache_len slots, at most max_cache_len - cond_len - 1 tokens (R/t3.R:753), stop token kept.
+#' Nothing is traced: the decode step is a replayed HIP graph on either path.
+t3_inference_traced <- function (model, cond, text_tokens, max_new_tokens = 1000,
+                                 temperature = 0.8, cfg_weight = 0.5, top_p = 0.95,
+                                 min_p = 0.05, repetition_penalty = 1.2, max_cache_len = 350L,
+                                 native = t3mi_model(attr(model, "t3_path")))
+{
+    cfg <- list(max_tokens = as.integer(max_new_tokens), temperature = as.double(temperature),
+                cfg_weight = as.double(cfg_weight), top_p = as.double(top_p), min_p = as.double(min_p),
+                rep_penalty = as.double(repetition_penalty))
+    r <- suppressWarnings(.t3mi_decode(model, cond, text_tokens, cfg, native, sampler = 0L,
+                                       max_cache_len = max_cache_len))
+    if (length(r$ids) && r$ids[length(r$ids)] == r$stop) message("EOS detected at step ", length(r$ids))
+    if (length(r$ids) > 0L) torch::torch_tensor(r$ids, dtype = torch::torch_long(), device = r$device)
+    else torch::torch_tensor(integer(0), device = r$device)
+}
+
 #' Same signature and return value as t3_inference_turbo (R/t3.R:1578-1580, 1662-1676): GPT-2 backbone, no CFG,
 #' top-k / top-p logit processors; the trailing stop token is removed.
 t3_inference_turbo <- function (model, cond, text_tokens, max_new_tokens = 1000,

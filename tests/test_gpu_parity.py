@@ -178,6 +178,18 @@ def test_tiny_stop_token_ends_generation_and_is_returned(tiny):
         assert list(s.tokens(0)) == [3, 4, dims.stop_speech_token]
 
 
+def test_traced_form_same_tokens_and_cache_limit(tiny):
+    """R/t3.R:685-871: same arithmetic and sampling rule as t3_inference on a fixed cache;
+    generation limited to max_cache_len - cond_len - 1 tokens (R/t3.R:753), stop token kept."""
+    dims, model, om = tiny
+    emb = synth.synth_embeds(2, 9, dims.hidden_size, 91)
+    ref = O.t3_inference(om, emb, O.SampleParams(max_new_tokens=14, top_p=0.0), keep_logits=False)
+    got = cb.t3_inference_traced(model, emb, max_new_tokens=14, top_p=0.0)
+    assert list(got) == ref.tokens
+    short = cb.t3_inference_traced(model, emb, max_new_tokens=14, top_p=0.0, max_cache_len=16)
+    assert list(short) == ref.tokens[: 16 - 9 - 1]
+
+
 def test_error_paths(tiny):
     dims, model, om = tiny
     emb = synth.synth_embeds(1, 4, dims.hidden_size, 1)
@@ -325,6 +337,58 @@ def test_tiny_80_rows_128_row_gemm_tiles(dtype, tol):
             outs = cb.t3_inference_batch(model, embs, max_new_tokens=n, top_p=0.0, mask_stop=True)
             for u in range(U):
                 assert list(outs[u]) == refs[u].tokens, f"utt {u}"
+    finally:
+        model.close()
+
+
+def test_tiny_280_rows_register_blocked_gemm():
+    """140 utterances x CFG pair = 280 activation rows with bf16 weights: from 256 rows up the linears run on
+    gemm_wide_kernel (256 x 128 / 256 x 64 / 128 x 64 block tiles; the second row chunk is only partly filled), as does
+    the prefill of the ~4000 prompt positions.  Teacher-forced against the oracle, every step within the bf16 bar."""
+    dims = synth.TINY
+    om = oracle_model(dims, 1234)
+    model = cb.load_t3(synth.ensure_checkpoint(dims, 1234), device=0, dtype="bf16",
+                       start_speech_token=dims.start_speech_token, stop_speech_token=dims.stop_speech_token)
+    try:
+        U, n = 140, 4
+        embs = [synth.synth_embeds(2, 4 + (7 * u) % 23, dims.hidden_size, 900 + u) for u in range(U)]
+        refs = [O.t3_inference(om, e, O.SampleParams(max_new_tokens=n, top_p=0.0), mask_stop=True, keep_logits=True) for e in embs]
+        forced = np.array([r.tokens for r in refs])
+        with cb.Session(model, embs, max_new_tokens=n, top_p=0.0, mask_stop=True, forced=forced) as s:
+            for i in range(n):
+                lg = s.logits()
+                for u in range(U):
+                    assert rel_err(lg[2 * u:2 * u + 2], refs[u].raw_logits[i]) < BF16_LOGIT_TOL, f"utt {u} step {i}"
+                s.decode(1)
+    finally:
+        model.close()
+
+
+def test_full_size_320_rows_register_blocked_gemm_vs_fp32():
+    """Full-size shapes, 160 utterances (320 rows): bf16 weights + bf16 KV through gemm_wide_kernel against the fp32
+    session of the same batch (exact-fp32 MFMA tiles), logits of the first and of the 4th step within the bf16 bar
+    (teacher-forced with the fp32 session's tokens)."""
+    dims = synth.FULL
+    U, n = 160, 3
+    embs = [synth.synth_embeds(2, 24, dims.hidden_size, 2000 + u) for u in range(U)]
+    path = synth.ensure_checkpoint(dims, 1234)
+    model = cb.load_t3(path, device=0)
+    try:
+        with cb.Session(model, embs, max_new_tokens=n + 1, top_p=0.0, mask_stop=True) as s:
+            a0 = s.logits()
+            s.decode(n)
+            a3 = s.logits()
+            forced = np.array([s.tokens(u)[:n] for u in range(U)])
+    finally:
+        model.close()
+    model = cb.load_t3(path, device=0, dtype="bf16")
+    try:
+        with cb.Session(model, embs, max_new_tokens=n + 1, top_p=0.0, mask_stop=True, forced=forced) as s:
+            b0 = s.logits()
+            s.decode(n)
+            b3 = s.logits()
+        assert rel_err(b0, a0) < BF16_LOGIT_TOL
+        assert rel_err(b3, a3) < BF16_LOGIT_TOL
     finally:
         model.close()
 

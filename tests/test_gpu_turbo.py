@@ -171,3 +171,24 @@ def test_turbo_70_rows_128_row_gemm_tiles(dtype, tol):
                 s.decode(1)
     finally:
         model.close()
+
+
+def test_turbo_300_rows_register_blocked_gemm():
+    """300 sentences, bf16 weights: the GPT-2 linears on gemm_wide_kernel (biases, GELU, LayerNorm rows, K-split c_proj,
+    a partly filled second row chunk).  Teacher-forced against the oracle within the bf16 bar."""
+    dims = synth.TURBO_TINY
+    om = turbo_oracle(dims, 4321)
+    model = _open(dims, 4321, dtype="bf16")
+    try:
+        U, n = 300, 3
+        embs = [synth.synth_embeds(1, 3 + (5 * u) % 19, dims.hidden_size, 1700 + u) for u in range(U)]
+        refs = [O.t3_inference_turbo(om, e, O.TurboParams(max_new_tokens=n, top_p=0.0), mask_stop=True) for e in embs]
+        forced = np.array([r.tokens for r in refs])
+        with cb.Session(model, embs, max_new_tokens=n, top_p=0.0, mask_stop=True, forced=forced) as s:
+            for i in range(n + 1):
+                lg = s.logits()
+                for u in range(U):
+                    assert rel_err(lg[u:u + 1], refs[u].raw_logits[i]) < 3e-2, f"sentence {u} step {i}"
+                s.decode(1)
+    finally:
+        model.close()
