@@ -448,7 +448,8 @@ template <> struct KvLoad<uint16_t> {
 };
 
 template <typename KVT, typename OT>
-__global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsArgs a) {
+__global__ __launch_bounds__(256, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kernel(AttnRowsArgs a) {   // bf16 cache: 4 waves per SIMD (128 VGPRs)
+
     __shared__ float sm_m[32], sm_l[32];
     __shared__ __attribute__((aligned(16))) float sm_acc[32][kHeadDim + 4];
     const int h = blockIdx.x, qi = blockIdx.y;
@@ -483,8 +484,9 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsArgs a) {
     using Raw = typename KvLoad<KVT>::Raw;
     Raw rka[kAhead], rkb[kAhead], rva[kAhead], rvb[kAhead];
     const int kfirst = wave * 8 + kg;
-    const int trips = (L + 31 - kfirst + 63) / 64;   // trips of this stream (same bound as `k0 < L + 31`)
-    auto issue = [&](int t, int slot) {
+    const int trips = (L + 63) / 64;   // block-uniform: streams whose last trip has no key left get masked scores
+    auto issue = [&](int t, auto SC) {
+        constexpr int slot = decltype(SC)::value;
         const int ka = kfirst + t * 64, kb = ka + 32;
         const size_t oa = (size_t)(ka < L ? ka : 0) * kHeadDim, ob = (size_t)(kb < L ? kb : 0) * kHeadDim;
         rka[slot] = KvLoad<KVT>::fetch(kp + oa);
@@ -492,45 +494,57 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsArgs a) {
         rva[slot] = KvLoad<KVT>::fetch(vp + oa);
         rvb[slot] = KvLoad<KVT>::fetch(vp + ob);
     };
+    // arithmetic of trip t on ring slot SC; no branch (an empty stream keeps m = -inf, l = 0, acc = 0)
+    auto consume = [&](int t, auto SC) {
+        constexpr int slot = decltype(SC)::value;
+        const int ka = kfirst + t * 64, kb = ka + 32;
+        const bool oka = ka < L, okb = kb < L;
+        float kva[8], kvb[8], vva[8], vvb[8];
+        KvLoad<KVT>::unpack(rka[slot], kva);
+        KvLoad<KVT>::unpack(rkb[slot], kvb);
+        KvLoad<KVT>::unpack(rva[slot], vva);
+        KvLoad<KVT>::unpack(rvb[slot], vvb);
+        float sa = 0.f, sb = 0.f;
 #pragma unroll
-    for (int u = 0; u < kAhead; ++u)
-        if (u < trips) issue(u, u);
-    for (int t0 = 0; t0 < trips; t0 += kAhead) {
-#pragma unroll
-        for (int u = 0; u < kAhead; ++u) {
-            const int t = t0 + u;
-            if (t < trips) {
-                const int ka = kfirst + t * 64, kb = ka + 32;
-                const bool oka = ka < L, okb = kb < L;
-                float kva[8], kvb[8], vva[8], vvb[8];
-                KvLoad<KVT>::unpack(rka[u], kva);
-                KvLoad<KVT>::unpack(rkb[u], kvb);
-                KvLoad<KVT>::unpack(rva[u], vva);
-                KvLoad<KVT>::unpack(rvb[u], vvb);
-                if (t + kAhead < trips) issue(t + kAhead, u);
-                float sa = 0.f, sb = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    sa = fmaf(qv[e], kva[e], sa);
-                    sb = fmaf(qv[e], kvb[e], sb);
-                }
-                // sum over the 8 lanes of the key (lanes kg*8 .. kg*8+7)
-                sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
-                sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
-                sa += __shfl_xor(sa, 4, 64); sb += __shfl_xor(sb, 4, 64);
-                sa = oka ? sa * 0.125f : -INFINITY;
-                sb = okb ? sb * 0.125f : -INFINITY;
-                const float mn = fmaxf(m_run, fmaxf(sa, sb));
-                if (mn > -INFINITY) {
-                    const float sc = expf(m_run - mn), pa = expf(sa - mn), pb = expf(sb - mn);
-                    l_run = fmaf(l_run, sc, pa + pb);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(pb, vvb[e], fmaf(pa, vva[e], acc[e] * sc));
-                    m_run = mn;
-                }
-            }
+        for (int e = 0; e < 8; ++e) {
+            sa = fmaf(qv[e], kva[e], sa);
+            sb = fmaf(qv[e], kvb[e], sb);
         }
+        // sum over the 8 lanes of the key (lanes kg*8 .. kg*8+7)
+        sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
+        sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
+        sa += __shfl_xor(sa, 4, 64); sb += __shfl_xor(sb, 4, 64);
+        sa = oka ? sa * 0.125f : -INFINITY;
+        sb = okb ? sb * 0.125f : -INFINITY;
+        const float mn = fmaxf(m_run, fmaxf(sa, sb));
+        const float mref = mn > -INFINITY ? mn : 0.f;   // nothing seen yet: all three factors become exp(-inf) = 0
+        const float sc = expf(m_run - mref), pa = expf(sa - mref), pb = expf(sb - mref);
+        l_run = fmaf(l_run, sc, pa + pb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pb, vvb[e], fmaf(pa, vva[e], acc[e] * sc));
+        m_run = mn;
+    };
+    using std::integral_constant;
+    static_assert(kAhead == 3, "the ring below is written out for three slots");
+    const integral_constant<int, 0> S0{};
+    const integral_constant<int, 1> S1{};
+    const integral_constant<int, 2> S2{};
+    // Consume a slot, refill it -- with NO branch around a load and a single loop exit.  A conditional refill makes
+    // the compiler wait for vmcnt(0) in every trip (it must cover the path on which nothing was issued), and a loop
+    // with several exits makes it copy the ring at the back edge (same wait): either way one full memory latency
+    // per trip, 22 us per block at L = 264.  So the trip count is padded to a multiple of kAhead, trips past the
+    // end are masked in consume() and their loads (and the last kAhead refills) are clamped to key 0 of the head:
+    // requests for one already cached line, no HBM traffic.
+    // (sched_barrier: the scheduler otherwise reorders the prologue's loads, slot 0 last, and the loop header then has
+    // to wait for everything.)
+#define T3K_SB() __builtin_amdgcn_sched_barrier(0)
+    issue(0, S0); T3K_SB(); issue(1, S1); T3K_SB(); issue(2, S2); T3K_SB();
+    for (int t = 0; t < trips; t += kAhead) {
+        consume(t, S0); T3K_SB(); issue(t + kAhead, S0); T3K_SB();
+        consume(t + 1, S1); T3K_SB(); issue(t + kAhead + 1, S1); T3K_SB();
+        consume(t + 2, S2); T3K_SB(); issue(t + kAhead + 2, S2); T3K_SB();
     }
+#undef T3K_SB
     // merge the 32 streams (4 waves x 8 key groups): stream id = wave*8 + kg
     const int sid = wave * 8 + kg;
     if (dc == 0) { sm_m[sid] = m_run; sm_l[sid] = l_run; }
@@ -583,65 +597,110 @@ __device__ __forceinline__ int tile32_feature(int t, int r32, int N) {
     return 32 * t + r32;
 }
 
+// Activation arithmetic by output type.  fp32 rows keep libm's expf / tanhf and IEEE division (the 1e-3 bar against the
+// fp32 oracle and greedy-token identity).  bf16 rows are rounded to 8 significant bits on store, so the hardware
+// exponential and reciprocal (about 1 ulp of fp32 each) are exact enough, and at 1024 rows the difference is
+// 3 us per gate_up launch chip-wide (about 30 VALU instructions per output against 8).
+template <typename T> __device__ __forceinline__ float act_sigmoid(float v) {
+    if constexpr (sizeof(T) == 2) return __frcp_rn(1.0f + __expf(-v));
+    else return 1.0f / (1.0f + expf(-v));
+}
+template <typename T> __device__ __forceinline__ float act_tanh(float v) {
+    if constexpr (sizeof(T) == 2) return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * v));   // exp overflow -> rcp(inf) = 0 -> 1
+    else return tanhf(v);
+}
+
+// Everything the epilogues READ from global memory is fetched before their first store: the stores may alias the
+// tables as far as the compiler knows, so a load inside the store loop waits for the previous store and the loop
+// runs at one memory latency per row (qkv at 1024 rows: 6.5 us of epilogue for 16 rows per lane).
+struct EpiRow { int pos, crow; };          // cache position and cache row of an activation row (EPI_ROPE_KV)
+struct EpiCol { float b0, b1; };           // bias of the two partner features of a column (0 without bias)
+
+template <int EPI>
+__device__ __forceinline__ EpiRow rows_pos(const GemmArgs& a, int mi) {
+    EpiRow e{-1, mi};
+    if (EPI == EPI_ROPE_KV && mi < a.M) {
+        e.pos = a.posmap[mi];
+        if (a.rowmap) e.crow = a.rowmap[mi];
+    }
+    return e;
+}
+template <int EPI>
+__device__ __forceinline__ EpiCol cols_bias(const GemmArgs& a, int tile, int nl) {
+    EpiCol c{0.f, 0.f};
+    if (a.bias != nullptr) {
+        const int f0 = tile32_feature<EPI>(tile, nl, a.N), f1 = tile32_feature<EPI>(tile, 16 + nl, a.N);
+        if (f0 < a.N) c.b0 = a.bias[f0];
+        if (f1 < a.N) c.b1 = a.bias[f1];
+    }
+    return c;
+}
+// RoPE factors of (row position, column pair) -- {1, 0} where nothing rotates (V tiles, no RoPE, inactive row)
+template <int EPI>
+__device__ __forceinline__ float2 rope_cs(const GemmArgs& a, int tile, int nl, int pos) {
+    float2 r{1.f, 0.f};
+    if (EPI == EPI_ROPE_KV && a.rope && pos >= 0 && (tile >> 1) / a.n_heads < 2) {
+        const int i = ((tile & 1) << 4) + nl;
+        r.x = a.rope_cos[(size_t)pos * kHeadDim + i];
+        r.y = a.rope_sin[(size_t)pos * kHeadDim + i];
+    }
+    return r;
+}
+
 // Epilogue of one output row mi for the PAIR of partner features that column nl of a 32-feature tile holds
 // (v0: sub-tile 0, v1: sub-tile 1; tile32_feature gives their feature ids).  Shared by gemm_rows_kernel and
-// gemm_wide_kernel.
+// gemm_wide_kernel.  Stores only (plus the residual read of the unsplit EPI_RESID form).
 template <int EPI, typename T>
-__device__ __forceinline__ void rows_epilogue(const GemmArgs& a, int tile, int nl, int mi, float v0, float v1, int kz, bool ksplit) {
+__device__ __forceinline__ void rows_epilogue(const GemmArgs& a, int tile, int nl, int mi, float v0, float v1, int kz, bool ksplit,
+                                              EpiRow er, EpiCol ec, float2 cs) {
     if (mi >= a.M) return;
     const int f0 = tile32_feature<EPI>(tile, nl, a.N), f1 = tile32_feature<EPI>(tile, 16 + nl, a.N);
     if (EPI == EPI_STORE || EPI == EPI_RESID) {
-        if (ksplit) {   // K split over blocks: fp32 partial slab of this K range
+        if (ksplit) {   // K split over blocks: fp32 partial slab of this K range (the fold adds the bias)
             float* pr = a.part + ((size_t)kz * a.M + mi) * a.N;
             if (f0 < a.N) pr[f0] = v0;
             if (f1 < a.N) pr[f1] = v1;
         } else {
             const size_t o = (size_t)mi * a.ldy;
             if (f0 < a.N) {
-                if (a.bias != nullptr) v0 = __fadd_rn(v0, a.bias[f0]);
+                if (a.bias != nullptr) v0 = __fadd_rn(v0, ec.b0);
                 a.y[o + f0] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o + f0], v0) : v0;
             }
             if (f1 < a.N) {
-                if (a.bias != nullptr) v1 = __fadd_rn(v1, a.bias[f1]);
+                if (a.bias != nullptr) v1 = __fadd_rn(v1, ec.b1);
                 a.y[o + f1] = (EPI == EPI_RESID) ? __fadd_rn(a.resid[o + f1], v1) : v1;
             }
         }
     } else if (EPI == EPI_GELU) {   // gelu_tanh(c_fc(x) + b)  (R/t3.R:1303-1304)
         T* yo = static_cast<T*>(a.yact) + (size_t)mi * a.N;
-        if (a.bias != nullptr) {
-            if (f0 < a.N) v0 = __fadd_rn(v0, a.bias[f0]);
-            if (f1 < a.N) v1 = __fadd_rn(v1, a.bias[f1]);
-        }
+        if (a.bias != nullptr) { v0 = __fadd_rn(v0, ec.b0); v1 = __fadd_rn(v1, ec.b1); }
         const float i0 = 0.7978845608028654f * (v0 + 0.044715f * v0 * v0 * v0);
         const float i1 = 0.7978845608028654f * (v1 + 0.044715f * v1 * v1 * v1);
-        if (f0 < a.N) Act<T>::store(yo + f0, 0.5f * v0 * (1.0f + tanhf(i0)));
-        if (f1 < a.N) Act<T>::store(yo + f1, 0.5f * v1 * (1.0f + tanhf(i1)));
+        if (f0 < a.N) Act<T>::store(yo + f0, 0.5f * v0 * (1.0f + act_tanh<T>(i0)));
+        if (f1 < a.N) Act<T>::store(yo + f1, 0.5f * v1 * (1.0f + act_tanh<T>(i1)));
     } else if (EPI == EPI_SWIGLU) {   // silu(gate) * up  (R/llama.R:302, 307)
-        const float sg = 1.0f / (1.0f + expf(-v0));
+        const float sg = act_sigmoid<T>(v0);
         Act<T>::store(static_cast<T*>(a.yact) + (size_t)mi * (a.N >> 1) + 16 * tile + nl, __fmul_rn(__fmul_rn(v0, sg), v1));
     } else {  // EPI_ROPE_KV
-        const int pos = a.posmap[mi];
+        const int pos = er.pos;
         if (pos < 0) return;
         const int H = a.n_heads, hm = tile >> 1, i = ((tile & 1) << 4) + nl;
         const int kind = hm / H, head = hm % H;
         float lo = v0, hi = v1;
         if (a.bias != nullptr) {
-            lo = __fadd_rn(lo, a.bias[hm * kHeadDim + i]);
-            hi = __fadd_rn(hi, a.bias[hm * kHeadDim + i + 32]);
+            lo = __fadd_rn(lo, ec.b0);
+            hi = __fadd_rn(hi, ec.b1);
         }
         if (kind < 2 && a.rope) {
-            const float cs = a.rope_cos[(size_t)pos * kHeadDim + i];
-            const float sn = a.rope_sin[(size_t)pos * kHeadDim + i];
-            const float nlo = __fadd_rn(__fmul_rn(lo, cs), __fmul_rn(-hi, sn));
-            const float nhi = __fadd_rn(__fmul_rn(hi, cs), __fmul_rn(lo, sn));
+            const float nlo = __fadd_rn(__fmul_rn(lo, cs.x), __fmul_rn(-hi, cs.y));
+            const float nhi = __fadd_rn(__fmul_rn(hi, cs.x), __fmul_rn(lo, cs.y));
             lo = nlo; hi = nhi;
         }
         if (kind == 0) {
             float* q = a.q + (size_t)mi * (H * kHeadDim) + head * kHeadDim;
             q[i] = lo; q[i + 32] = hi;
         } else {
-            const int crow = a.rowmap ? a.rowmap[mi] : mi;
-            const size_t co = (((size_t)crow * H + head) * a.max_len + pos) * kHeadDim;
+            const size_t co = (((size_t)er.crow * H + head) * a.max_len + pos) * kHeadDim;
             if (a.kv_bf16) {
                 uint16_t* cb = static_cast<uint16_t*>(kind == 1 ? a.kcache : a.vcache) + co;
                 cb[i] = f2bf(lo); cb[i + 32] = f2bf(hi);
@@ -653,7 +712,7 @@ __device__ __forceinline__ void rows_epilogue(const GemmArgs& a, int tile, int n
     }
 }
 
-template <int EPI, typename T, bool ADIRECT>
+template <int EPI, typename T, bool ADIRECT, int SC>
 __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte piece: 8 (bf16) or 4 (fp32)
     constexpr int KC = 16 * E, LD = KC + E;  // 256-byte step rows, row stride 272 B: the 16 rows of a fragment read fall in distinct banks
@@ -666,7 +725,10 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     const int nl = lane & 15, g = lane >> 4;
     const int tile = blockIdx.x, m0 = blockIdx.y * 128, kz = blockIdx.z;
     const int K = a.K;
-    const int S = (K / KC) / (int)gridDim.z;   // steps of this block
+    // steps of this block.  SC > 0: known at compile time (the decode shapes: 8 or 4 steps), so that every `s < S`
+    // below folds away -- with run-time conditions around the ring refills the compiler waits for vmcnt(0) in every
+    // step (it must cover the path on which nothing was issued) and the register rings hide nothing.
+    const int S = SC > 0 ? SC : (K / KC) / (int)gridDim.z;
     unsigned long long* dbg = a.dbg != nullptr && tid == 0
                                   ? a.dbg + 4 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
     if (dbg) dbg[0] = wall_clock64();
@@ -821,9 +883,18 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     if (dbg) dbg[2] = wall_clock64();
     if (!live) return;
     // accumulator layout: row = g*4 + r of the wave's 16 rows, column nl of the sub-tile
+    {
+        const EpiCol ec = cols_bias<EPI>(a, tile, nl);
+        EpiRow er[4];
+        float2 cs[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        rows_epilogue<EPI, T>(a, tile, nl, m0 + wave * 16 + g * 4 + r, acc0[r], acc1[r], kz, gridDim.z > 1);
+        for (int r = 0; r < 4; ++r) er[r] = rows_pos<EPI>(a, m0 + wave * 16 + g * 4 + r);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[r] = rope_cs<EPI>(a, tile, nl, er[r].pos);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            rows_epilogue<EPI, T>(a, tile, nl, m0 + wave * 16 + g * 4 + r, acc0[r], acc1[r], kz, gridDim.z > 1, er[r], ec, cs[r]);
+    }
     if (dbg) dbg[3] = wall_clock64();
 }
 
@@ -859,6 +930,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a, int tiles32,
     const int m0 = chunk * BM, kz = blockIdx.y;
     const int K = a.K;
     const int S = (K / 64) / (int)gridDim.y;             // 64-k steps of this block
+    unsigned long long* dbg = a.dbg != nullptr && tid == 0 && blockIdx.x + gridDim.x * blockIdx.y < 4096
+                                  ? a.dbg + 4 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y) : nullptr;
+    if (dbg) dbg[0] = wall_clock64();
     const int kbeg = kz * S * 64;
     const T* Wp = static_cast<const T*>(a.W);
     const T* Ap = static_cast<const T*>(a.A);
@@ -913,6 +987,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a, int tiles32,
         for (int p = 0; p < PW; ++p) rw[0][p] = *reinterpret_cast<const uint4*>(srcW[p] + (size_t)kWW * 64);
     }
     __syncthreads();
+    if (dbg) dbg[1] = wall_clock64();
     // One step.  U = s % 4 comes as a type so that the ring slots are literal indices (the rings stay in registers).
     // CK = false is the steady state: no branches at all -- the tile of step s + 1 is always staged (after the last
     // step it lands in a buffer nobody reads) and the refill loads clamp their step to S - 1 -- so that the compiler
@@ -969,19 +1044,39 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a, int tiles32,
     step(integral_constant<int, 0>{}, std::true_type{}, s0);
     step(integral_constant<int, 1>{}, std::true_type{}, s0 + 1);
     step(integral_constant<int, 2>{}, std::true_type{}, s0 + 2);
+    if (dbg) dbg[2] = wall_clock64();
     // wave (wm, wn): rows m0 + 16 (MT wm + i) + 4 g + r; sub-tiles 2 tt / 2 tt + 1 are the partner halves of 32-feature
     // tile blk NT + wn NT/2 + tt
+    {
+        constexpr int TT = NT / 2;
+        EpiCol ec[TT];
+        EpiRow er[MT][4];
+        float2 cs[MT][4][TT];
 #pragma unroll
-    for (int tt = 0; tt < NT / 2; ++tt) {
-        const int t = blk * NT + wn * (NT / 2) + tt;
-        if (t >= tiles32) continue;
+        for (int tt = 0; tt < TT; ++tt) ec[tt] = cols_bias<EPI>(a, min(blk * NT + wn * TT + tt, tiles32 - 1), nl);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) er[i][r] = rows_pos<EPI>(a, m0 + (wm * MT + i) * 16 + g * 4 + r);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                rows_epilogue<EPI, T>(a, t, nl, m0 + (wm * MT + i) * 16 + g * 4 + r, acc[i][2 * tt][r], acc[i][2 * tt + 1][r], kz,
-                                      gridDim.y > 1);
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) cs[i][r][tt] = rope_cs<EPI>(a, blk * NT + wn * TT + tt, nl, er[i][r].pos);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    const int t = blk * NT + wn * TT + tt;
+                    if (t < tiles32)
+                        rows_epilogue<EPI, T>(a, t, nl, m0 + (wm * MT + i) * 16 + g * 4 + r, acc[i][2 * tt][r], acc[i][2 * tt + 1][r], kz,
+                                              gridDim.y > 1, er[i][r], ec[tt], cs[i][r][tt]);
+                }
     }
+    if (dbg) dbg[3] = wall_clock64();
 }
 
 // y[m][i] = resid[m][i] + bias[i] + sum_s part[s][m][i], s ascending (the K-split of gemm_rows_kernel).
@@ -1026,12 +1121,23 @@ hipError_t launch_gemm_rows_v(const GemmArgs& a, hipStream_t s) {
     hipError_t ed = hipGetDevice(&dev);
     if (ed != hipSuccess) return ed;
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, ADIRECT>),
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, ADIRECT, 0>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e0 != hipSuccess) return e0;
+        if (!ADIRECT) {
+            e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, false, 8>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e0 != hipSuccess) return e0;
+            e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, false, 4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e0 != hipSuccess) return e0;
+        }
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, ADIRECT>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
+    const int steps = a.K / KC / ks;
+    if (!ADIRECT && steps == 8) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 8>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
+    else if (!ADIRECT && steps == 4) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 4>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, ADIRECT, 0>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     hipError_t e = hipGetLastError();
     if (a.ks_out != nullptr) *a.ks_out = ks;
     if (e != hipSuccess || ks == 1) return e;
@@ -1095,6 +1201,15 @@ hipError_t launch_gemm_wide(const GemmArgs& a, hipStream_t s) {
     if (((tiles32 + 3) / 4) * c4 >= 128) return launch_gemm_wide_v<EPI, 4, 4>(a, tiles32, s);
     if (((tiles32 + 1) / 2) * c4 >= 128) return launch_gemm_wide_v<EPI, 4, 2>(a, tiles32, s);
     return launch_gemm_wide_v<EPI, 2, 2>(a, tiles32, s);
+}
+
+// Does the register-blocked kernel leave enough blocks for M rows?  (>= 128 before any K split with one of its
+// shapes, or M >= 512.)  Measured at 256 rows (gemm_micro): gate_up 17.9 vs 20.2 us and head 18.3 vs 29.9 us in its
+// favour, qkv 14.2 vs 11.6 and o_proj 10.5 vs 8.9 against (96 and 32 blocks).
+inline bool gemm_wide_pays(const GemmArgs& a, int epilogue) {
+    if (a.M >= 512) return true;
+    const long long tiles32 = epilogue == EPI_ROPE_KV ? (a.N / kHeadDim) * 2 : (a.N + 31) / 32;
+    return ((tiles32 + 1) / 2) * ((a.M + 127) / 128) >= 128;
 }
 
 template <typename G, int MT, int KS, int EPI>
@@ -1161,7 +1276,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
     // with K split over the waves win (8 rows, Turbo batched: 5156 vs 3516 tok/s)
     // more than T3MI_GEMM_WIDE_MIN - 1 rows of bf16 operands: the register-blocked kernel (gemm_wide_kernel)
     static const int wide_min = [] { const char* v = getenv("T3MI_GEMM_WIDE_MIN"); return v ? atoi(v) : 256; }();
-    if (wdtype == 1 && !gen1 && wide_min > 0 && a.M >= wide_min && a.K % 128 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0)) {
+    if (wdtype == 1 && !gen1 && wide_min > 0 && a.M >= wide_min && a.K % 128 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0) &&
+        gemm_wide_pays(a, epilogue)) {
         switch (epilogue) {
             case EPI_STORE: return launch_gemm_wide<EPI_STORE>(a, s);
             case EPI_RESID: return launch_gemm_wide<EPI_RESID>(a, s);
