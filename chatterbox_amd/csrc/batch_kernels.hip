@@ -249,14 +249,15 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(float* __restrict__ x
     __shared__ float sred[4];
     const int m = blockIdx.x, tid = threadIdx.x;
     float* xr = x + (size_t)m * d;
-    float4 v[kV];
+    float4 v[kV], wv[kV];   // the norm weight is requested with the row: a load after the barrier would add one memory latency
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < kV; ++j) {
         const int i = 4 * tid + j * 1024;
-        v[j] = float4{0.f, 0.f, 0.f, 0.f};
+        v[j] = wv[j] = float4{0.f, 0.f, 0.f, 0.f};
         if (i < d) {
             float4 t = *reinterpret_cast<const float4*>(xr + i);
+            wv[j] = *reinterpret_cast<const float4*>(w + i);
             if (ks > 0) {
                 float4 pp[8];   // all partials requested at once, then added in order
 #pragma unroll
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(float* __restrict__ x
     for (int j = 0; j < kV; ++j) {
         const int i = 4 * tid + j * 1024;
         if (i < d) {
-            const float4 ww = *reinterpret_cast<const float4*>(w + i);
+            const float4 ww = wv[j];
             AT* o = out + (size_t)m * d + i;
             const float y0 = __fmul_rn(ww.x, __fmul_rn(v[j].x, rs)), y1 = __fmul_rn(ww.y, __fmul_rn(v[j].y, rs));
             const float y2 = __fmul_rn(ww.z, __fmul_rn(v[j].z, rs)), y3 = __fmul_rn(ww.w, __fmul_rn(v[j].w, rs));
@@ -312,14 +313,16 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(float* __restrict__
     __shared__ float sred[8];
     const int m = blockIdx.x, tid = threadIdx.x;
     float* xr = x + (size_t)m * d;
-    float4 v[kV];
+    float4 v[kV], wv[kV], bv[kV];   // weight and bias requested with the row (see rmsnorm_rows_kernel)
     float sm = 0.f;
 #pragma unroll
     for (int j = 0; j < kV; ++j) {
         const int i = 4 * tid + j * 1024;
-        v[j] = float4{0.f, 0.f, 0.f, 0.f};
+        v[j] = wv[j] = bv[j] = float4{0.f, 0.f, 0.f, 0.f};
         if (i < d) {
             float4 t = *reinterpret_cast<const float4*>(xr + i);
+            wv[j] = *reinterpret_cast<const float4*>(w + i);
+            bv[j] = *reinterpret_cast<const float4*>(b + i);
             if (ks > 0) {
                 float4 pp[8];   // all partials requested at once, then added in order
 #pragma unroll
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(float* __restrict__
     for (int j = 0; j < kV; ++j) {
         const int i = 4 * tid + j * 1024;
         if (i < d) {
-            const float4 ww = *reinterpret_cast<const float4*>(w + i), bb = *reinterpret_cast<const float4*>(b + i);
+            const float4 ww = wv[j], bb = bv[j];
             AT* o = out + (size_t)m * d + i;
             const float y0 = __fadd_rn(__fmul_rn(__fmul_rn(v[j].x - mean, rs), ww.x), bb.x);
             const float y1 = __fadd_rn(__fmul_rn(__fmul_rn(v[j].y - mean, rs), ww.y), bb.y);
@@ -1131,12 +1134,16 @@ hipError_t launch_gemm_rows_v(const GemmArgs& a, hipStream_t s) {
             e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, false, 4>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e0 != hipSuccess) return e0;
+            e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, false, 2>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e0 != hipSuccess) return e0;
         }
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const int steps = a.K / KC / ks;
     if (!ADIRECT && steps == 8) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 8>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     else if (!ADIRECT && steps == 4) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 4>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
+    else if (!ADIRECT && steps == 2) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 2>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     else hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, ADIRECT, 0>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     hipError_t e = hipGetLastError();
     if (a.ks_out != nullptr) *a.ks_out = ks;
