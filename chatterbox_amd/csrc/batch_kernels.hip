@@ -450,6 +450,14 @@ template <> struct KvLoad<uint16_t> {
     }
 };
 
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <typename KVT> __device__ __forceinline__ float attn_exp(float v) {
+    if constexpr (sizeof(KVT) == 2) return __expf(v);
+    else return expf(v);
+}
+
 template <typename KVT, typename OT>
 __global__ __launch_bounds__(256, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kernel(AttnRowsArgs a) {   // bf16 cache: 4 waves per SIMD (128 VGPRs)
 
@@ -513,15 +521,17 @@ __global__ __launch_bounds__(256, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kerne
             sa = fmaf(qv[e], kva[e], sa);
             sb = fmaf(qv[e], kvb[e], sb);
         }
-        // sum over the 8 lanes of the key (lanes kg*8 .. kg*8+7)
-        sa += __shfl_xor(sa, 1, 64); sb += __shfl_xor(sb, 1, 64);
-        sa += __shfl_xor(sa, 2, 64); sb += __shfl_xor(sb, 2, 64);
-        sa += __shfl_xor(sa, 4, 64); sb += __shfl_xor(sb, 4, 64);
+        // sum over the 8 lanes of the key (lanes kg*8 .. kg*8+7): lane ^ 1, lane ^ 2 inside the quad, then the other
+        // quad of the 8 -- as DPP moves (VALU, no LDS round trip; __shfl_xor compiles to ds_bpermute), same sums
+        sa += dpp_f32<0xB1>(sa); sb += dpp_f32<0xB1>(sb);     // quad_perm [1,0,3,2]
+        sa += dpp_f32<0x4E>(sa); sb += dpp_f32<0x4E>(sb);     // quad_perm [2,3,0,1]
+        sa += dpp_f32<0x141>(sa); sb += dpp_f32<0x141>(sb);   // row_half_mirror: lane 7 - i of the 8, i.e. the other quad's sum
         sa = oka ? sa * 0.125f : -INFINITY;
         sb = okb ? sb * 0.125f : -INFINITY;
         const float mn = fmaxf(m_run, fmaxf(sa, sb));
         const float mref = mn > -INFINITY ? mn : 0.f;   // nothing seen yet: all three factors become exp(-inf) = 0
-        const float sc = expf(m_run - mref), pa = expf(sa - mref), pb = expf(sb - mref);
+        // bf16 cache (values carry 8 significant bits): the hardware exponential; fp32 cache: libm's
+        const float sc = attn_exp<KVT>(m_run - mref), pa = attn_exp<KVT>(sa - mref), pb = attn_exp<KVT>(sb - mref);
         l_run = fmaf(l_run, sc, pa + pb);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = fmaf(pb, vvb[e], fmaf(pa, vva[e], acc[e] * sc));
