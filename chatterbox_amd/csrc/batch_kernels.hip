@@ -474,7 +474,11 @@ __global__ __launch_bounds__(256, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kerne
         return;
     }
     const int L = pos + 1;
+#ifdef T3K_ATTN_EXP   // diagnostic builds only (results wrong): 1 = every block reads cache row 0, 2 = rows 0..7
+    const int crow = T3K_ATTN_EXP == 1 ? 0 : (qi & 7);
+#else
     const int crow = a.rowmap ? a.rowmap[qi] : qi;
+#endif
     const size_t base = ((size_t)crow * a.n_heads + h) * a.max_len * kHeadDim;
     const KVT* kp = static_cast<const KVT*>(a.kcache) + base + dc * 8;
     const KVT* vp = static_cast<const KVT*>(a.vcache) + base + dc * 8;
