@@ -24,6 +24,7 @@ namespace {
 
 constexpr int kHeadDim = 64;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ uint16_t f2bf(float f) {
@@ -519,12 +520,16 @@ __global__ __launch_bounds__(256, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kerne
         KvLoad<KVT>::unpack(rkb[slot], kvb);
         KvLoad<KVT>::unpack(rva[slot], vva);
         KvLoad<KVT>::unpack(rvb[slot], vvb);
-        float sa = 0.f, sb = 0.f;
+        // packed fp32 multiply-adds (v_pk_fma_f32: two lanes of arithmetic per instruction): element pairs (e, e + 1)
+        // of both keys; the per-key dot product is the sum of an even and an odd chain
+        f32x2 da = {0.f, 0.f}, db = {0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sa = fmaf(qv[e], kva[e], sa);
-            sb = fmaf(qv[e], kvb[e], sb);
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2 q2 = {qv[e], qv[e + 1]};
+            da = __builtin_elementwise_fma(q2, f32x2{kva[e], kva[e + 1]}, da);
+            db = __builtin_elementwise_fma(q2, f32x2{kvb[e], kvb[e + 1]}, db);
         }
+        float sa = da.x + da.y, sb = db.x + db.y;
         // sum over the 8 lanes of the key (lanes kg*8 .. kg*8+7): lane ^ 1, lane ^ 2 inside the quad, then the other
         // quad of the 8 -- as DPP moves (VALU, no LDS round trip; __shfl_xor compiles to ds_bpermute), same sums
         sa += dpp_f32<0xB1>(sa); sb += dpp_f32<0xB1>(sb);     // quad_perm [1,0,3,2]
@@ -537,8 +542,13 @@ __global__ __launch_bounds__(256, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kerne
         // bf16 cache (values carry 8 significant bits): the hardware exponential; fp32 cache: libm's
         const float sc = attn_exp<KVT>(m_run - mref), pa = attn_exp<KVT>(sa - mref), pb = attn_exp<KVT>(sb - mref);
         l_run = fmaf(l_run, sc, pa + pb);
+        const f32x2 sc2 = {sc, sc}, pa2 = {pa, pa}, pb2 = {pb, pb};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pb, vvb[e], fmaf(pa, vva[e], acc[e] * sc));
+        for (int e = 0; e < 8; e += 2) {
+            f32x2 a2 = {acc[e], acc[e + 1]};
+            a2 = __builtin_elementwise_fma(pb2, f32x2{vvb[e], vvb[e + 1]}, __builtin_elementwise_fma(pa2, f32x2{vva[e], vva[e + 1]}, a2 * sc2));
+            acc[e] = a2.x; acc[e + 1] = a2.y;
+        }
         m_run = mn;
     };
     using std::integral_constant;

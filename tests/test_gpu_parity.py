@@ -113,8 +113,11 @@ def test_tiny_top_p_one_keeps_the_support(tiny_peaked):
         s.decode(1)
         ids, pr = s.dist(0)
     t = ref.tails[0]
-    assert len(ids) > dims.speech_vocab // 2
     k = 64
+    # where the running sum first rounds above 1.0 moves with the last bits of the logits (431 or 917 entries kept,
+    # depending on the summation order of the prefill): what must hold is that only negligible mass is cut
+    assert len(ids) >= 4 * k
+    assert float(np.sum(np.asarray(t.sorted_probs, dtype=np.float64)[len(ids):])) < 1e-5
     assert list(ids[:k]) == [int(i) for i in t.sorted_idx[:k]]
     assert np.allclose(pr[:k], np.asarray(t.sorted_probs[:k], dtype=np.float64), rtol=2e-3)
 
