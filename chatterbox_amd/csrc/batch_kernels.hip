@@ -1161,6 +1161,11 @@ hipError_t launch_gemm_rows_v(const GemmArgs& a, hipStream_t s) {
             e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, false, 2>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e0 != hipSuccess) return e0;
+            if (sizeof(T) == 4) {
+                e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, false, sizeof(T) == 4 ? 16 : 0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e0 != hipSuccess) return e0;
+            }
         }
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
@@ -1168,6 +1173,8 @@ hipError_t launch_gemm_rows_v(const GemmArgs& a, hipStream_t s) {
     if (!ADIRECT && steps == 8) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 8>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     else if (!ADIRECT && steps == 4) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 4>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     else if (!ADIRECT && steps == 2) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 2>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
+    else if (!ADIRECT && sizeof(T) == 4 && steps == 16)   // fp32 operands: 64-k steps, K = 1024 is 16 of them
+        hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, sizeof(T) == 4 ? 16 : 0>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     else hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, ADIRECT, 0>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     hipError_t e = hipGetLastError();
     if (a.ks_out != nullptr) *a.ks_out = ks;
