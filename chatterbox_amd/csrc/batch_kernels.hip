@@ -150,11 +150,14 @@ __global__ __launch_bounds__(KS * 64) void mfma_gemm_kernel(GemmArgs a) {
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = G::mma(as[u][mt], bs[u], acc[mt]);
             }
     };
+    // The refills are unconditional (load_stage clamps its k-block to the last one, so the two stages past the end
+    // re-request cached lines): a condition around them makes the compiler wait for vmcnt(0) before every
+    // compute_stage, i.e. no overlap at all ("exact wait counts").
     load_stage(0, b0, a0);
     for (int j0 = 0; j0 < nkb; j0 += 2 * UN) {
-        if (j0 + UN < nkb) load_stage(j0 + UN, b1, a1);
+        load_stage(j0 + UN, b1, a1);
         compute_stage(j0, b0, a0);
-        if (j0 + 2 * UN < nkb) load_stage(j0 + 2 * UN, b0, a0);
+        load_stage(j0 + 2 * UN, b0, a0);
         compute_stage(j0 + UN, b1, a1);
     }
     // K-partials -> LDS: C layout col = lane&15, row = (lane>>4)*4 + reg
@@ -739,13 +742,16 @@ __device__ __forceinline__ void rows_epilogue(const GemmArgs& a, int tile, int n
     }
 }
 
-template <int EPI, typename T, bool ADIRECT, int SC>
+template <int EPI, typename T, bool ADIRECT, int SC, int AP = 4>
 __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte piece: 8 (bf16) or 4 (fp32)
     constexpr int KC = 16 * E, LD = KC + E;  // 256-byte step rows, row stride 272 B: the 16 rows of a fragment read fall in distinct banks
     // LDS rows per step: ADIRECT stages only the 32 weight rows (the activation fragments go global -> registers),
     // otherwise 128 activation rows + 32 weight rows
-    constexpr int kARows = ADIRECT ? 0 : 128, kRows = kARows + 32;
+    // AP: staging passes of 32 activation rows (4 = 128 rows; 1 = launches of <= 32 rows, which then write 12 KB to LDS
+    // per step instead of 40 and keep a quarter of the activation ring).  ADIRECT keeps its 4 fragment pieces.
+    constexpr int NP = ADIRECT ? 4 : AP;
+    constexpr int kARows = ADIRECT ? 0 : 32 * AP, kRows = kARows + 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char tl_raw[];
     T* tl = reinterpret_cast<T*>(tl_raw);   // [2][kRows][LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -772,7 +778,7 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     // segments per instruction, every segment requested four times: 3-4x slower.)
     const int srow = tid >> 4, spiece = tid & 15;
     const T* src[5];
-    const bool live = m0 + wave * 16 < a.M;
+    const bool live = m0 + wave * 16 < a.M && (ADIRECT || wave * 16 < 32 * AP);
     if constexpr (ADIRECT) {
         int r = m0 + wave * 16 + nl;
         r = r < a.M ? r : a.M - 1;
@@ -780,7 +786,7 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
         src[1] = src[2] = src[3] = src[0];
     } else {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NP; ++p) {
             int r = m0 + p * 32 + srow;
             r = r < a.M ? r : a.M - 1;
             src[p] = Ap + (size_t)r * K + kbeg + spiece * E;
@@ -799,7 +805,7 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     // non-temporal weight loads measured 1-2 % slower here, gate_up 21.1 -> 21.7 us, down 11.3 -> 12.3); the activation rows come
     // from L2 and run kDA steps ahead.
     constexpr int kDW = 8, kDA = 3;
-    uint4 rw[kDW], ra[kDA][4];
+    uint4 rw[kDW], ra[kDA][NP];
     auto load_a = [&](int step, int p) -> uint4 {   // piece p of the thread's activation data of a step
         if constexpr (ADIRECT) return *reinterpret_cast<const uint4*>(src[0] + (size_t)step * KC + p * (4 * E));
         else return *reinterpret_cast<const uint4*>(src[p] + (size_t)step * KC);
@@ -809,13 +815,13 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
 #pragma unroll
     for (int q = 0; q < kDA; ++q)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) ra[q][p] = (q < S && (!ADIRECT || live)) ? load_a(q, p) : uint4{0u, 0u, 0u, 0u};
+        for (int p = 0; p < NP; ++p) ra[q][p] = (q < S && (!ADIRECT || live)) ? load_a(q, p) : uint4{0u, 0u, 0u, 0u};
     if constexpr (!ADIRECT) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(&tl[soff + p * 32 * LD]) = ra[0][p];
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(&tl[soff + p * 32 * LD]) = ra[0][p];
         if (kDA < S) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) ra[0][p] = load_a(kDA, p);
+            for (int p = 0; p < NP; ++p) ra[0][p] = load_a(kDA, p);
         }
     }
     *reinterpret_cast<uint4*>(&tl[soff + kARows * LD]) = rw[0];
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
                     T* dst = tl + ((s + 1) & 1) * (kRows * LD) + soff;
                     if constexpr (!ADIRECT) {
 #pragma unroll
-                        for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(dst + p * 32 * LD) = ra[ua][p];
+                        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(dst + p * 32 * LD) = ra[ua][p];
                     }
                     *reinterpret_cast<uint4*>(dst + kARows * LD) = rw[uw];
                 }
@@ -894,12 +900,12 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
                 if constexpr (ADIRECT) {
                     if (live && s + kDA < S) {
 #pragma unroll
-                        for (int p = 0; p < 4; ++p) ra[ua][p] = load_a(s + kDA, p);
+                        for (int p = 0; p < NP; ++p) ra[ua][p] = load_a(s + kDA, p);
                     }
                 } else {
                     if (s + 1 + kDA < S) {
 #pragma unroll
-                        for (int p = 0; p < 4; ++p) ra[ua][p] = load_a(s + 1 + kDA, p);
+                        for (int p = 0; p < NP; ++p) ra[ua][p] = load_a(s + 1 + kDA, p);
                     }
                 }
                 if (s + 1 + kDW < S) rw[uw] = *reinterpret_cast<const uint4*>(src[4] + (size_t)(s + 1 + kDW) * KC);
@@ -1170,6 +1176,13 @@ hipError_t launch_gemm_rows_v(const GemmArgs& a, hipStream_t s) {
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const int steps = a.K / KC / ks;
+    // <= 32 rows of bf16 operands (a handful of utterances, Turbo's batch of sentences): one staging pass
+    if (!ADIRECT && sizeof(T) == 2 && a.M <= 32 && (steps == 8 || steps == 4 || steps == 2)) {
+        constexpr int lds1 = 2 * 64 * (128 + 8) * 2;
+        if (steps == 8) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 8, sizeof(T) == 2 ? 1 : 4>), dim3(tiles, 1, ks), dim3(512), lds1, s, a);
+        else if (steps == 4) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 4, sizeof(T) == 2 ? 1 : 4>), dim3(tiles, 1, ks), dim3(512), lds1, s, a);
+        else hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 2, sizeof(T) == 2 ? 1 : 4>), dim3(tiles, 1, ks), dim3(512), lds1, s, a);
+    } else
     if (!ADIRECT && steps == 8) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 8>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     else if (!ADIRECT && steps == 4) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 4>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
     else if (!ADIRECT && steps == 2) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 2>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);

@@ -344,6 +344,57 @@ def test_tiny_80_rows_128_row_gemm_tiles(dtype, tol):
         model.close()
 
 
+@pytest.mark.parametrize("U", [3, 5, 16])
+def test_tiny_bf16_few_rows_one_staging_pass(U):
+    """6, 10 and 32 activation rows with bf16 weights: the 128-row GEMM kernel in its one-staging-pass form (<= 32 rows),
+    ragged prompts, teacher-forced against the oracle within the bf16 bar."""
+    dims = synth.TINY
+    om = oracle_model(dims, 1234)
+    model = cb.load_t3(synth.ensure_checkpoint(dims, 1234), device=0, dtype="bf16",
+                       start_speech_token=dims.start_speech_token, stop_speech_token=dims.stop_speech_token)
+    try:
+        n = 5
+        embs = [synth.synth_embeds(2, 5 + (11 * u) % 17, dims.hidden_size, 1300 + u) for u in range(U)]
+        refs = [O.t3_inference(om, e, O.SampleParams(max_new_tokens=n, top_p=0.0), mask_stop=True) for e in embs]
+        forced = np.array([r.tokens for r in refs])
+        with cb.Session(model, embs, max_new_tokens=n, top_p=0.0, mask_stop=True, forced=forced) as s:
+            for i in range(n):
+                lg = s.logits()
+                for u in range(U):
+                    assert rel_err(lg[2 * u:2 * u + 2], refs[u].raw_logits[i]) < BF16_LOGIT_TOL, f"utt {u} step {i}"
+                s.decode(1)
+    finally:
+        model.close()
+
+
+def test_full_size_bf16_16_rows_vs_fp32():
+    """Full-size shapes, 8 utterances (16 rows): bf16 weights through the one-staging-pass GEMM (8-, 4- and 2-step
+    compile-time forms) against the fp32 session of the same batch, first and 4th step, teacher-forced."""
+    dims = synth.FULL
+    U, n = 8, 3
+    embs = [synth.synth_embeds(2, 20 + u, dims.hidden_size, 2500 + u) for u in range(U)]
+    path = synth.ensure_checkpoint(dims, 1234)
+    model = cb.load_t3(path, device=0)
+    try:
+        with cb.Session(model, embs, max_new_tokens=n + 1, top_p=0.0, mask_stop=True) as s:
+            a0 = s.logits()
+            s.decode(n)
+            a3 = s.logits()
+            forced = np.array([s.tokens(u)[:n] for u in range(U)])
+    finally:
+        model.close()
+    model = cb.load_t3(path, device=0, dtype="bf16")
+    try:
+        with cb.Session(model, embs, max_new_tokens=n + 1, top_p=0.0, mask_stop=True, forced=forced) as s:
+            b0 = s.logits()
+            s.decode(n)
+            b3 = s.logits()
+        assert rel_err(b0, a0) < BF16_LOGIT_TOL
+        assert rel_err(b3, a3) < BF16_LOGIT_TOL
+    finally:
+        model.close()
+
+
 def test_tiny_280_rows_register_blocked_gemm():
     """140 utterances x CFG pair = 280 activation rows with bf16 weights: from 256 rows up the linears run on
     gemm_wide_kernel (256 x 128 / 256 x 64 / 128 x 64 block tiles; the second row chunk is only partly filled), as does

@@ -192,3 +192,24 @@ def test_turbo_300_rows_register_blocked_gemm():
                 s.decode(1)
     finally:
         model.close()
+
+
+def test_turbo_bf16_8_sentences_one_staging_pass():
+    """cfg 5's batched shape at reduced size: 8 sentences (8 rows), bf16 weights -- the one-staging-pass form of the
+    128-row GEMM with biases, GELU and LayerNorm rows.  Teacher-forced against the oracle within the bf16 bar."""
+    dims = synth.TURBO_TINY
+    om = turbo_oracle(dims, 4321)
+    model = _open(dims, 4321, dtype="bf16")
+    try:
+        U, n = 8, 5
+        embs = [synth.synth_embeds(1, 6 + 3 * u, dims.hidden_size, 2700 + u) for u in range(U)]
+        refs = [O.t3_inference_turbo(om, e, O.TurboParams(max_new_tokens=n, top_p=0.0), mask_stop=True) for e in embs]
+        forced = np.array([r.tokens for r in refs])
+        with cb.Session(model, embs, max_new_tokens=n, top_p=0.0, mask_stop=True, forced=forced) as s:
+            for i in range(n + 1):
+                lg = s.logits()
+                for u in range(U):
+                    assert rel_err(lg[u:u + 1], refs[u].raw_logits[i]) < 3e-2, f"sentence {u} step {i}"
+                s.decode(1)
+    finally:
+        model.close()
