@@ -258,7 +258,8 @@ __global__ __launch_bounds__(512) void gemv_kernel(const void* __restrict__ pW, 
             for (int q = 0; q < NK; ++q) WT::load(pW, off + (size_t)q * kWave * E, w[j][q]);
         }
     };
-    if (c < n_chunks) load_chunk(c);
+    load_chunk(c);   // unconditional: load_chunk clamps its rows (a wave without a chunk re-requests the last row), and a
+                     // condition around these loads makes the compiler wait for vmcnt(0) before the prologue math
     T3K_STAMP(a, gwave, 7);   // every load of the first chunk issued (nothing waited for yet)
 
 #ifdef T3K_PREFETCH_EXPERIMENTS
