@@ -148,8 +148,10 @@ __global__ __launch_bounds__(512) void gemv_kernel(const void* __restrict__ pW, 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                                          // [R][K], PRO_NORM / PRO_ATTN
     float* part = smem + (PRO != PRO_PLAIN ? R * K : 0);       // [NW][max(ROWS,2)][R] scratch
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    // block size from the kernel arguments (scalar loads), not blockDim: the compiler fetched the byte of blockDim it needed
+    // with a VECTOR load from the implicit arguments and waited for it before issuing anything else (KSPLIT = 4)
+    const int tid = threadIdx.x, nthr = a.waves * 64;
+    const int lane = tid & 63, wave = tid >> 6, nw = a.waves;
     const int grp = wave / KSPLIT, kpart = wave % KSPLIT, ngrp = nw / KSPLIT;
     const int kbase = kpart * KW;
 
@@ -1353,7 +1355,9 @@ hipError_t launch_gemv_t(const GemvArgs& a, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(nw * 64), lds, s, a.W, a.x, a.ln_w, a.resid, a.rowpos, a.rope_cur, a.N, n_chunks, a);
+    GemvArgs al = a;
+    al.waves = nw;   // the kernel reads its block size from here
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(nw * 64), lds, s, a.W, a.x, a.ln_w, a.resid, a.rowpos, a.rope_cur, a.N, n_chunks, al);
     return hipGetLastError();
 }
 
