@@ -173,14 +173,15 @@ def test_turbo_70_rows_128_row_gemm_tiles(dtype, tol):
         model.close()
 
 
-def test_turbo_300_rows_register_blocked_gemm():
-    """300 sentences, bf16 weights: the GPT-2 linears on gemm_wide_kernel (biases, GELU, LayerNorm rows, K-split c_proj,
-    a partly filled second row chunk).  Teacher-forced against the oracle within the bf16 bar."""
+@pytest.mark.parametrize("U,n", [(300, 3), (257, 1)])
+def test_turbo_300_rows_register_blocked_gemm(U, n):
+    """300 (257) sentences, bf16 weights: the GPT-2 linears on gemm_wide_kernel (biases, GELU, LayerNorm rows, K-split
+    c_proj, a partly filled second row chunk -- one single row of it at 257).  Teacher-forced against the oracle
+    within the bf16 bar."""
     dims = synth.TURBO_TINY
     om = turbo_oracle(dims, 4321)
     model = _open(dims, 4321, dtype="bf16")
     try:
-        U, n = 300, 3
         embs = [synth.synth_embeds(1, 3 + (5 * u) % 19, dims.hidden_size, 1700 + u) for u in range(U)]
         refs = [O.t3_inference_turbo(om, e, O.TurboParams(max_new_tokens=n, top_p=0.0), mask_stop=True) for e in embs]
         forced = np.array([r.tokens for r in refs])
