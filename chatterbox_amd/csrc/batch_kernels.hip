@@ -387,35 +387,6 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(float* __restrict__
     }
 }
 
-// ---- merge of the split-softmax attention partials into the o_proj activation rows ----------------------
-template <typename AT>
-__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
-                                                         const float* __restrict__ pacc, const int* __restrict__ posmap,
-                                                         AT* __restrict__ out, int H, int n_split_max, int kps) {
-    const int qi = blockIdx.x;
-    const int pos = posmap[qi];
-    const int d = H * kHeadDim;
-    for (int i = threadIdx.x; i < d; i += 256) {
-        float o = 0.f;
-        if (pos >= 0) {
-            const int head = i >> 6, dd = i & 63;
-            const int ns = pos / kps + 1;
-            const size_t b = ((size_t)qi * H + head) * n_split_max;
-            float M = -INFINITY;
-            for (int s = 0; s < ns; ++s) M = fmaxf(M, pm[b + s]);
-            float den = 0.f;
-            for (int s = 0; s < ns; ++s) {
-                const float ws = expf(pm[b + s] - M);
-                den = fmaf(ws, pl[b + s], den);
-                o = fmaf(ws, pacc[(b + s) * kHeadDim + dd], o);
-            }
-            o /= den;
-        }
-        Act<AT>::store(out + (size_t)qi * d + i, o);
-    }
-}
-
-
 // ---- many-row attention: one block per (query item, head) ----------------------------------------------------
 // (R/llama.R:257-264, src/t3_decode.cpp:151-160.)  With >= 8 rows x 16 heads there are enough (item, head) pairs
 // to fill the chip without splitting the keys over blocks, so the softmax finishes inside the block and the output
@@ -478,11 +449,7 @@ __global__ __launch_bounds__(256, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kerne
         return;
     }
     const int L = pos + 1;
-#ifdef T3K_ATTN_EXP   // diagnostic builds only (results wrong): 1 = every block reads cache row 0, 2 = rows 0..7
-    const int crow = T3K_ATTN_EXP == 1 ? 0 : (qi & 7);
-#else
     const int crow = a.rowmap ? a.rowmap[qi] : qi;
-#endif
     const size_t base = ((size_t)crow * a.n_heads + h) * a.max_len * kHeadDim;
     const KVT* kp = static_cast<const KVT*>(a.kcache) + base + dc * 8;
     const KVT* vp = static_cast<const KVT*>(a.vcache) + base + dc * 8;
@@ -742,16 +709,15 @@ __device__ __forceinline__ void rows_epilogue(const GemmArgs& a, int tile, int n
     }
 }
 
-template <int EPI, typename T, bool ADIRECT, int SC, int AP = 4>
+template <int EPI, typename T, int SC, int AP = 4>
 __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte piece: 8 (bf16) or 4 (fp32)
     constexpr int KC = 16 * E, LD = KC + E;  // 256-byte step rows, row stride 272 B: the 16 rows of a fragment read fall in distinct banks
-    // LDS rows per step: ADIRECT stages only the 32 weight rows (the activation fragments go global -> registers),
-    // otherwise 128 activation rows + 32 weight rows
+    // LDS rows per step: 32 * AP activation rows + 32 weight rows.
     // AP: staging passes of 32 activation rows (4 = 128 rows; 1 = launches of <= 32 rows, which then write 12 KB to LDS
-    // per step instead of 40 and keep a quarter of the activation ring).  ADIRECT keeps its 4 fragment pieces.
-    constexpr int NP = ADIRECT ? 4 : AP;
-    constexpr int kARows = ADIRECT ? 0 : 32 * AP, kRows = kARows + 32;
+    // per step instead of 40 and keep a quarter of the activation ring).
+    constexpr int NP = AP;
+    constexpr int kARows = 32 * AP, kRows = kARows + 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char tl_raw[];
     T* tl = reinterpret_cast<T*>(tl_raw);   // [2][kRows][LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -770,27 +736,16 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     const T* Ap = static_cast<const T*>(a.A);
 
     // staging: thread t moves the 16 B piece t & 15 of tile rows (t >> 4) + 32 p, so 16 consecutive lanes fetch one
-    // whole 256-byte run.  !ADIRECT: p = 0..3 activation rows, p = 4 the weight rows.
-    // ADIRECT: only the weight rows are staged; wave w reads the MFMA fragments of its 16 activation rows straight
-    // from global memory (L2): lane (n, g) takes the 16 bytes g of the 64-byte run j of its row for MFMA (group) j, so
-    // one load instruction covers 16 rows x one whole 64-byte segment and every segment is requested exactly once.
-    // (A first attempt gave lane (n, g) the 64 bytes g of the 256-byte run -- four 16-byte slivers of four different
-    // segments per instruction, every segment requested four times: 3-4x slower.)
+    // whole 256-byte run: p = 0..AP-1 activation rows, src[4] the weight rows.  (Reading the activation fragments
+    // straight from global memory and staging only the weights was measured 7 % slower end to end: DESIGN.md 3.2.)
     const int srow = tid >> 4, spiece = tid & 15;
     const T* src[5];
-    const bool live = m0 + wave * 16 < a.M && (ADIRECT || wave * 16 < 32 * AP);
-    if constexpr (ADIRECT) {
-        int r = m0 + wave * 16 + nl;
-        r = r < a.M ? r : a.M - 1;
-        src[0] = Ap + (size_t)r * K + kbeg + g * E;   // + step * KC + j * 4E
-        src[1] = src[2] = src[3] = src[0];
-    } else {
+    const bool live = m0 + wave * 16 < a.M && wave * 16 < 32 * AP;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            int r = m0 + p * 32 + srow;
-            r = r < a.M ? r : a.M - 1;
-            src[p] = Ap + (size_t)r * K + kbeg + spiece * E;
-        }
+    for (int p = 0; p < NP; ++p) {
+        int r = m0 + p * 32 + srow;
+        r = r < a.M ? r : a.M - 1;
+        src[p] = Ap + (size_t)r * K + kbeg + spiece * E;
     }
     {
         int sf = tile32_feature<EPI>(tile, srow, a.N);
@@ -807,22 +762,19 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     constexpr int kDW = 8, kDA = 3;
     uint4 rw[kDW], ra[kDA][NP];
     auto load_a = [&](int step, int p) -> uint4 {   // piece p of the thread's activation data of a step
-        if constexpr (ADIRECT) return *reinterpret_cast<const uint4*>(src[0] + (size_t)step * KC + p * (4 * E));
-        else return *reinterpret_cast<const uint4*>(src[p] + (size_t)step * KC);
+        return *reinterpret_cast<const uint4*>(src[p] + (size_t)step * KC);
     };
 #pragma unroll
     for (int q = 0; q < kDW; ++q) rw[q] = (q < S) ? *reinterpret_cast<const uint4*>(src[4] + (size_t)q * KC) : uint4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int q = 0; q < kDA; ++q)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) ra[q][p] = (q < S && (!ADIRECT || live)) ? load_a(q, p) : uint4{0u, 0u, 0u, 0u};
-    if constexpr (!ADIRECT) {
+        for (int p = 0; p < NP; ++p) ra[q][p] = q < S ? load_a(q, p) : uint4{0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(&tl[soff + p * 32 * LD]) = ra[0][p];
-        if (kDA < S) {
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(&tl[soff + p * 32 * LD]) = ra[0][p];
+    if (kDA < S) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) ra[0][p] = load_a(kDA, p);
-        }
+        for (int p = 0; p < NP; ++p) ra[0][p] = load_a(kDA, p);
     }
     *reinterpret_cast<uint4*>(&tl[soff + kARows * LD]) = rw[0];
     if (kDW < S) rw[0] = *reinterpret_cast<const uint4*>(src[4] + (size_t)kDW * KC);
@@ -834,26 +786,18 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
         for (int u = 0; u < 24; ++u) {
             const int s = s0 + u;
             if (s < S) {   // block-uniform
-                // !ADIRECT: ring slot (s+1) % kDA holds the staging pieces of step s+1; ADIRECT: slot s % kDA holds the
-                // fragments of step s itself
-                const int ua = ADIRECT ? u % kDA : (u + 1) % kDA, uw = (u + 1) % kDW;
-#if defined(T3K_GEMM_EXP) && (T3K_GEMM_EXP == 1 || T3K_GEMM_EXP == 3)
-                if (false) {
-#else
+                // ring slot (s+1) % kDA holds the staging pieces of step s+1
+                const int ua = (u + 1) % kDA, uw = (u + 1) % kDW;
                 if (live) {
-#endif
-                    // lane (nl, g) of the weight rows reads the 16 bytes g of run j (ADIRECT, as its activation fragment) or
-                    // piece j of the 64 bytes g (both operands from LDS): either way a fixed permutation of the dot product's
-                    // terms over the MFMA k slots, the same for both operands
+                    // lane (nl, g) reads piece j of the 64 bytes g of its row for MFMA j (both operands from LDS): a fixed
+                    // permutation of the dot product's terms over the MFMA k slots, the same for both operands
                     const T* tb = tl + (s & 1) * (kRows * LD);
                     const T* ab = tb + (wave * 16 + nl) * LD + g * (4 * E);
-                    const T* wb = tb + (kARows + nl) * LD + (ADIRECT ? g * E : g * (4 * E));
-                    constexpr int jstride = ADIRECT ? 4 * E : E;
+                    const T* wb = tb + (kARows + nl) * LD + g * (4 * E);
+                    constexpr int jstride = E;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        uint4 araw;
-                        if constexpr (ADIRECT) araw = ra[ua][j];
-                        else araw = *reinterpret_cast<const uint4*>(ab + j * E);
+                        const uint4 araw = *reinterpret_cast<const uint4*>(ab + j * E);
                         if constexpr (sizeof(T) == 2) {
                             const bf16x8 av = __builtin_bit_cast(bf16x8, araw);
                             const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wb + j * jstride);
@@ -878,35 +822,18 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
                 }
                 // after the step's MFMAs: tile of step s+1 -> the LDS buffer last read in step s-1, then refill the ring
                 // slots.  (Order within the step is immaterial: staging before or after the MFMAs measures the same.
-                // gemm_micro, gate_up at 128 rows, 8 steps, !ADIRECT: barriers + global loads alone 2.75 us; + staging
+                // gemm_micro, gate_up at 128 rows, 8 steps: barriers + global loads alone 2.75 us; + staging
                 // writes 2.77; + fragment reads and MFMAs 4.30; all three 5.43 -- the LDS serves 136 KB per step and the
                 // reads and writes contend for it.)
-                // (T3K_GEMM_EXP: timing diagnostics for scripts/micro/gemm_micro only, results are wrong: 1 = no fragment
-                // reads / MFMAs, 2 = no LDS staging writes, 3 = neither: barriers and global loads alone)
-#if !defined(T3K_GEMM_EXP) || (T3K_GEMM_EXP != 2 && T3K_GEMM_EXP != 3)
                 if (s + 1 < S) {
                     T* dst = tl + ((s + 1) & 1) * (kRows * LD) + soff;
-                    if constexpr (!ADIRECT) {
 #pragma unroll
-                        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(dst + p * 32 * LD) = ra[ua][p];
-                    }
+                    for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(dst + p * 32 * LD) = ra[ua][p];
                     *reinterpret_cast<uint4*>(dst + kARows * LD) = rw[uw];
                 }
-#else
-                if (s + 1 < S) {   // keep the loaded registers alive without the LDS traffic
-                    asm volatile("" ::"v"(ra[ua][0].x), "v"(ra[ua][1].x), "v"(ra[ua][2].x), "v"(ra[ua][3].x), "v"(rw[uw].x));
-                }
-#endif
-                if constexpr (ADIRECT) {
-                    if (live && s + kDA < S) {
+                if (s + 1 + kDA < S) {
 #pragma unroll
-                        for (int p = 0; p < NP; ++p) ra[ua][p] = load_a(s + kDA, p);
-                    }
-                } else {
-                    if (s + 1 + kDA < S) {
-#pragma unroll
-                        for (int p = 0; p < NP; ++p) ra[ua][p] = load_a(s + 1 + kDA, p);
-                    }
+                    for (int p = 0; p < NP; ++p) ra[ua][p] = load_a(s + 1 + kDA, p);
                 }
                 if (s + 1 + kDW < S) rw[uw] = *reinterpret_cast<const uint4*>(src[4] + (size_t)(s + 1 + kDW) * KC);
                 __syncthreads();
@@ -1132,8 +1059,8 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(float* __restrict__ 
     y[o] = resid != nullptr ? __fadd_rn(r, v) : v;
 }
 
-template <int EPI, typename T, bool ADIRECT>
-hipError_t launch_gemm_rows_v(const GemmArgs& a, hipStream_t s) {
+template <int EPI, typename T>
+hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s) {
     constexpr int KC = 16 * (16 / (int)sizeof(T));   // the kernel's step: 128 (bf16) or 64 (fp32) k
     int tiles;
     if (EPI == EPI_ROPE_KV) tiles = (a.N / kHeadDim) * 2;
@@ -1147,48 +1074,39 @@ hipError_t launch_gemm_rows_v(const GemmArgs& a, hipStream_t s) {
                (size_t)(2 * ks) * a.M * a.N <= a.part_floats)
             ks *= 2;
     }
-    constexpr int lds = 2 * (ADIRECT ? 32 : 160) * (128 + 8) * 2;   // two step tiles: 87,040 B, or 17,408 B (weights only)
+    constexpr int lds = 2 * 160 * (128 + 8) * 2;   // two step tiles: 87,040 B
+    constexpr int SC16 = sizeof(T) == 4 ? 16 : 0;  // fp32 operands: 64-k steps, K = 1024 is 16 of them
     // the attribute belongs to the (kernel, device) pair: one flag per EPI instantiation and device
     static bool attr_done[64] = {};   // (static in a function template: one array per <EPI, T>)
     int dev = 0;
     hipError_t ed = hipGetDevice(&dev);
     if (ed != hipSuccess) return ed;
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, ADIRECT, 0>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e0 != hipSuccess) return e0;
-        if (!ADIRECT) {
-            e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, false, 8>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const void* fns[5] = {reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, 0>),
+                              reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, 8>),
+                              reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, 4>),
+                              reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, 2>),
+                              reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, SC16>)};
+        for (const void* fn : fns) {
+            hipError_t e0 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e0 != hipSuccess) return e0;
-            e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, false, 4>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e0 != hipSuccess) return e0;
-            e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, false, 2>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e0 != hipSuccess) return e0;
-            if (sizeof(T) == 4) {
-                e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, false, sizeof(T) == 4 ? 16 : 0>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                if (e0 != hipSuccess) return e0;
-            }
         }
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const int steps = a.K / KC / ks;
+    const dim3 grid(tiles, chunks, ks), block(512);
     // <= 32 rows of bf16 operands (a handful of utterances, Turbo's batch of sentences): one staging pass
-    if (!ADIRECT && sizeof(T) == 2 && a.M <= 32 && (steps == 8 || steps == 4 || steps == 2)) {
+    if (sizeof(T) == 2 && a.M <= 32 && (steps == 8 || steps == 4 || steps == 2)) {
         constexpr int lds1 = 2 * 64 * (128 + 8) * 2;
-        if (steps == 8) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 8, sizeof(T) == 2 ? 1 : 4>), dim3(tiles, 1, ks), dim3(512), lds1, s, a);
-        else if (steps == 4) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 4, sizeof(T) == 2 ? 1 : 4>), dim3(tiles, 1, ks), dim3(512), lds1, s, a);
-        else hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 2, sizeof(T) == 2 ? 1 : 4>), dim3(tiles, 1, ks), dim3(512), lds1, s, a);
-    } else
-    if (!ADIRECT && steps == 8) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 8>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
-    else if (!ADIRECT && steps == 4) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 4>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
-    else if (!ADIRECT && steps == 2) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, 2>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
-    else if (!ADIRECT && sizeof(T) == 4 && steps == 16)   // fp32 operands: 64-k steps, K = 1024 is 16 of them
-        hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, false, sizeof(T) == 4 ? 16 : 0>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, ADIRECT, 0>), dim3(tiles, chunks, ks), dim3(512), lds, s, a);
+        constexpr int AP1 = sizeof(T) == 2 ? 1 : 4;
+        if (steps == 8) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 8, AP1>), dim3(tiles, 1, ks), block, lds1, s, a);
+        else if (steps == 4) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 4, AP1>), dim3(tiles, 1, ks), block, lds1, s, a);
+        else hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 2, AP1>), dim3(tiles, 1, ks), block, lds1, s, a);
+    } else if (steps == 8) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 8>), grid, block, lds, s, a);
+    else if (steps == 4) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 4>), grid, block, lds, s, a);
+    else if (steps == 2) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 2>), grid, block, lds, s, a);
+    else if (sizeof(T) == 4 && steps == 16) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, SC16>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 0>), grid, block, lds, s, a);
     hipError_t e = hipGetLastError();
     if (a.ks_out != nullptr) *a.ks_out = ks;
     if (e != hipSuccess || ks == 1) return e;
@@ -1196,17 +1114,6 @@ hipError_t launch_gemm_rows_v(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(fold_partials_kernel, dim3(a.M, (a.N + 255) / 256), dim3(256), 0, s, a.y, EPI == EPI_RESID ? a.resid : nullptr, a.part, ks,
                        a.bias, a.M, a.N, a.ldy);
     return hipGetLastError();
-}
-
-template <int EPI, typename T>
-hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s) {
-    // T3MI_GEMM_ADIRECT=1: activation fragments straight from global memory, only the weights through LDS (17 KB of
-    // LDS and 72 KB of LDS traffic per step instead of 87 KB and 136 KB).  Parity-green but SLOWER at 128 rows
-    // (gemm_micro: gate_up 13.9 vs 12.0 us, first tile 5.4 vs 3.6 us, loop 6.0 vs 5.4 us; batch-64 step 2.88 vs
-    // 2.68 ms): 16 rows x 64 B per load instruction costs the vector-memory pipe more than whole 256-byte runs cost
-    // the LDS.  Kept selectable for A/B measurements.
-    static const bool adirect = [] { const char* v = getenv("T3MI_GEMM_ADIRECT"); return v && v[0] == '1'; }();
-    return adirect ? launch_gemm_rows_v<EPI, T, true>(a, s) : launch_gemm_rows_v<EPI, T, false>(a, s);
 }
 
 template <int EPI, int MT, int NT>
@@ -1320,14 +1227,12 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
         (a.N != 3 * a.n_heads * kHeadDim || !a.posmap || !a.q || !a.kcache || !a.vcache || a.max_len <= 0 ||
          (a.rope && (!a.rope_cos || !a.rope_sin))))
         return hipErrorInvalidValue;
-    static const bool gen1 = [] { const char* v = getenv("T3MI_GEMM_GEN1"); return v && v[0] == '1'; }();
-    // second-generation kernel: bf16 operands, or fp32 operands (T3MI_GEMM_GEN1=1 selects the first generation)
-    // fp32 operands take it from 64 rows up: its block is 128 rows x 32 features whatever M is, and the exact-fp32 MFMA is
+    // 128-row tile kernel (gemm_rows_kernel): bf16 operands, or fp32 operands from 64 rows up: its block is 128 rows x 32 features whatever M is, and the exact-fp32 MFMA is
     // 16x slower than the bf16 one, so with few rows (one live wave per block) the first generation's 16-feature tiles
     // with K split over the waves win (8 rows, Turbo batched: 5156 vs 3516 tok/s)
-    // more than T3MI_GEMM_WIDE_MIN - 1 rows of bf16 operands: the register-blocked kernel (gemm_wide_kernel)
-    static const int wide_min = [] { const char* v = getenv("T3MI_GEMM_WIDE_MIN"); return v ? atoi(v) : 256; }();
-    if (wdtype == 1 && !gen1 && wide_min > 0 && a.M >= wide_min && a.K % 128 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0) &&
+    // 256 rows or more of bf16 operands: the register-blocked kernel (gemm_wide_kernel) where it leaves enough blocks
+    constexpr int wide_min = 256;
+    if (wdtype == 1 && a.M >= wide_min && a.K % 128 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0) &&
         gemm_wide_pays(a, epilogue)) {
         switch (epilogue) {
             case EPI_STORE: return launch_gemm_wide<EPI_STORE>(a, s);
@@ -1337,7 +1242,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
             case EPI_ROPE_KV: return launch_gemm_wide<EPI_ROPE_KV>(a, s);
         }
     }
-    if ((wdtype == 1 || (wdtype == 0 && a.M >= 64)) && !gen1 && a.K % 256 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0)) {
+    if ((wdtype == 1 || (wdtype == 0 && a.M >= 64)) && a.K % 256 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0)) {
         if (wdtype == 1) {
             switch (epilogue) {
                 case EPI_STORE: return launch_gemm_rows<EPI_STORE, uint16_t>(a, s);
@@ -1387,18 +1292,6 @@ hipError_t launch_layernorm_rows(float* x, const float* w, const float* b, float
 hipError_t launch_fold_partials(float* x, const float* part, int ks, const float* pbias, int M, int d, hipStream_t s) {
     if (!x || !part || ks < 1 || M <= 0 || d <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(fold_partials_kernel, dim3(M, (d + 255) / 256), dim3(256), 0, s, x, x, part, ks, pbias, M, d, d);
-    return hipGetLastError();
-}
-
-hipError_t launch_attn_merge(const float* pm, const float* pl, const float* pacc, const int* posmap, void* out, int M,
-                             int H, int n_split_max, int kps, int act_bf16, hipStream_t s) {
-    if (!pm || !pl || !pacc || !posmap || !out || M <= 0) return hipErrorInvalidValue;
-    if (act_bf16)
-        hipLaunchKernelGGL(attn_merge_kernel<uint16_t>, dim3(M), dim3(256), 0, s, pm, pl, pacc, posmap,
-                           static_cast<uint16_t*>(out), H, n_split_max, kps);
-    else
-        hipLaunchKernelGGL(attn_merge_kernel<float>, dim3(M), dim3(256), 0, s, pm, pl, pacc, posmap,
-                           static_cast<float*>(out), H, n_split_max, kps);
     return hipGetLastError();
 }
 

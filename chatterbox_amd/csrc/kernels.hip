@@ -106,19 +106,6 @@ struct BF16W {
 //   STORE/RESID : n = ROWS*c + j
 //   ROPE_KV     : both halves (i, i+32) of rotate_half pairs of one head of q, k or v
 //   SWIGLU      : gate rows and the matching up rows (F = N/2 apart)
-// launch counter of the decode chain, read by the L2 prefetcher as a throttle (a hint: never a data hand-off)
-__device__ __forceinline__ void bump_progress(int* p) {
-#ifdef T3K_PREFETCH_EXPERIMENTS
-    if (p != nullptr) {
-        const int old = __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // diagnostic (T3MI_PF_DEBUG): the hardware XCD block 0 of launch number `old` ran on
-        if (p[kPfLogOn]) p[kPfXccLog + (old & 1023)] = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u);
-    }
-#else
-    (void)p;
-#endif
-}
-
 template <int EPI, int ROWS>
 __device__ __forceinline__ int chunk_row(int c, int j, int N) {
     constexpr int HP = ROWS / 2;  // pairs per chunk (ROPE / SWIGLU)
@@ -162,7 +149,6 @@ __global__ __launch_bounds__(512) void gemv_kernel(const void* __restrict__ pW, 
 
     [[maybe_unused]] const int gwave = (int)blockIdx.x * nw + wave;
     T3K_STAMP(a, gwave, 0);
-    if (blockIdx.x == 0 && tid == 0) bump_progress(a.progress);
 
     // ---- 1. small L2-resident operands FIRST.  Vector-memory results return in issue order, so anything
     // requested after the weight stream only becomes usable once the weights have landed; requested
@@ -263,67 +249,6 @@ __global__ __launch_bounds__(512) void gemv_kernel(const void* __restrict__ pW, 
     load_chunk(c);   // unconditional: load_chunk clamps its rows (a wave without a chunk re-requests the last row), and a
                      // condition around these loads makes the compiler wait for vmcnt(0) before the prologue math
     T3K_STAMP(a, gwave, 7);   // every load of the first chunk issued (nothing waited for yet)
-
-#ifdef T3K_PREFETCH_EXPERIMENTS
-    // ---- 2b. L2 prefetch for later launches.  A batch-1 decode kernel streams only a few MB, so its fixed ramp
-    // (first-byte latency, tail) dominates; the weights of the NEXT launches do not depend on this launch's result,
-    // so every wave touches one dword per 128-byte line of its share of them, from a block on the XCD whose L2 the
-    // consuming blocks will read through (block b of every launch runs on XCD b % 8: round-robin placement; a wrong
-    // guess costs speed only).  Lines fetched this way survive the kernel boundary
-    // (scripts/micro/l2_prefetch_micro.hip: a 33.6 MB launch drops from 5.8 to 2.1 us).  Issued AFTER this launch's
-    // own loads: results return in issue order, so nothing of this launch waits behind them except the wave's exit.
-    constexpr int kPfMax = 3;
-    float pfv[2][kPfMax];
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
-#pragma unroll
-        for (int u = 0; u < kPfMax; ++u) pfv[jb][u] = 0.f;
-        const PfJob& J = a.pf[jb];
-        if (J.item.W != nullptr) {
-            const PfItem& it = J.item;
-            const int slot = (int)blockIdx.x & 7;
-            const int nranks = ((int)gridDim.x - slot + 7) >> 3;                // blocks of this launch on this XCD
-            const int worker = ((int)blockIdx.x >> 3) * nw + wave, nworkers = nranks * nw;
-            const int lpr = (int)(it.row_bytes >> 7);                          // 128-byte lines per row
-            const int nb = (it.grid - slot + 7) >> 3;                          // consuming blocks on this XCD
-            const int lg_lpr = __builtin_ctz(lpr), lg_rows = __builtin_ctz(it.rows), lg_ngrp = __builtin_ctz(it.ngrp);
-            const int lg_lpu = lg_lpr + lg_rows + lg_ngrp;                     // lines of one block pass of the consumer
-            const int hp = it.rows >> 1, lg_hp = hp > 0 ? __builtin_ctz(hp) : 0;
-            const int passes = (it.n_chunks + it.grid * it.ngrp - 1) / (it.grid * it.ngrp);
-            const int total_lines = nb > 0 ? (passes * nb) << lg_lpu : 0;
-            const int n_wl = (total_lines + 63) >> 6;
-            const int wl_end = (int)(((long long)n_wl * J.end16) >> 4);
-            const char* Wb = static_cast<const char*>(it.W);
-#pragma unroll
-            for (int u = 0; u < kPfMax; ++u) {
-                const int wl = (int)(((long long)n_wl * J.begin16) >> 4) + worker + u * nworkers;
-                const int line = wl * 64 + lane;
-                if (wl < wl_end && line < total_lines) {
-                    const unsigned unit = (unsigned)line >> lg_lpu;
-                    const int l = line & ((1 << lg_lpu) - 1);
-                    const unsigned pass = unit / (unsigned)nb, bl = unit - pass * (unsigned)nb;
-                    const int blk = slot + 8 * (int)bl;
-                    const int cc = ((blk + (int)pass * it.grid) << lg_ngrp) + (l >> (lg_lpr + lg_rows));
-                    const int jj = (l >> lg_lpr) & (it.rows - 1);
-                    if (cc < it.n_chunks) {
-                        int row;
-                        if (it.kind == 1) {            // rotate_half pairs of one head (chunk_row<EPI_ROPE_KV>)
-                            const int lg_ph = 5 - lg_hp;
-                            row = ((cc >> lg_ph) << 6) + ((cc & ((1 << lg_ph) - 1)) << lg_hp) + (jj & (hp - 1)) + ((jj >> lg_hp) << 5);
-                        } else if (it.kind == 2) {     // gate rows and the matching up rows (chunk_row<EPI_SWIGLU>)
-                            row = (jj >> lg_hp) * (it.N >> 1) + (cc << lg_hp) + (jj & (hp - 1));
-                        } else {
-                            row = (cc << lg_rows) + jj;
-                        }
-                        if (row < it.N)
-                            pfv[jb][u] = *reinterpret_cast<const float*>(Wb + (size_t)row * it.row_bytes + ((size_t)(l & (lpr - 1)) << 7));
-                    }
-                }
-            }
-        }
-    }
-
-#endif
 
     // ---- 3. prologue math while the weights are in flight
 #ifdef T3K_STAMPS
@@ -655,17 +580,6 @@ __global__ __launch_bounds__(512) void gemv_kernel(const void* __restrict__ pW, 
         }
     }
     T3K_STAMP(a, gwave, 4);   // stores issued
-#ifdef T3K_PREFETCH_EXPERIMENTS
-    {
-        // keeps the prefetch loads alive; N is never negative (checked at launch), the compiler cannot know it
-        float t = 0.f;
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int u = 0; u < kPfMax; ++u) t += pfv[jb][u];
-        if (pN < 0) a.y[0] = t;
-    }
-#endif
 }
 
 // ---- single-query attention over the KV cache, split along the keys ---------------------------------
@@ -681,7 +595,6 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnArgs a) {
     const int gwave = (((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
 #endif
     T3K_STAMP(a, gwave, 0);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) bump_progress(a.progress);
     const int pos = a.rowpos[r];
     if (pos < 0) return;
     const int L = pos + 1;
@@ -841,7 +754,6 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
     const int u = blockIdx.x;
     const int tid = threadIdx.x;
     const int V = a.V;
-    if (u == 0 && tid == 0) bump_progress(a.progress);
     if (a.done[u]) {
         if (tid < a.rpu) a.rowpos[u * a.rpu + tid] = -1;
         return;
@@ -1192,130 +1104,6 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
     }
 }
 
-// ---- L2 weight prefetcher ----------------------------------------------------------------------------
-// The batch-1 decode chain is a sequence of short dependent kernels; each one's weight slice is only a few
-// microseconds of HBM time, so the fixed ramp (first-byte latency, tail) of every launch dominates.  Weights do not
-// depend on the activations, so a small side kernel walks the step's weight matrices in launch order and touches
-// one dword of every 128-byte line from a block ON THE XCD whose L2 the consuming blocks will read through
-// (blocks are placed round-robin over the 8 XCDs; slot_of_xcc comes from a placement census at open time).
-// Lines fetched this way survive the kernel boundary (scripts/micro/l2_prefetch_micro.hip: a 33.6 MB launch drops
-// from 5.8 to 2.1 us).  The prefetcher is throttled by the chain's launch counter so it stays `lookahead` launches
-// ahead (L2 is 4 MiB per XCD).  It never produces data: a stale counter or a wrong placement guess only costs speed.
-__device__ __forceinline__ int chunk_row_rt(int kind, int rows, int c, int j, int N) {
-    const int hp = rows >> 1;
-    if (kind == 1) {
-        const int per_head = 32 / hp;
-        const int hm = c / per_head, i0 = (c % per_head) * hp;
-        return hm * kHeadDim + i0 + (j % hp) + (j / hp) * 32;
-    }
-    if (kind == 2) return (j / hp) * (N >> 1) + hp * c + (j % hp);
-    return rows * c + j;
-}
-
-__device__ __forceinline__ int hw_xcc_id() {
-    // HW_REG_XCC_ID (id 20), bits 3:0
-    return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u);
-}
-
-__global__ __launch_bounds__(256) void xcc_census_kernel(int* out) {
-    if (threadIdx.x == 0) out[blockIdx.x] = hw_xcc_id();
-}
-
-// kPfUnroll = wave-loads (8 KB each) a prefetcher wave keeps in flight: with the block count it bounds the bytes
-// queued in the memory system, and with them the extra latency the chain's own small loads see
-template <int kPfUnroll>
-__global__ __launch_bounds__(256) void weight_prefetch_kernel(const PfItem* __restrict__ plan, int n_items, int* state, int base,
-                                                              int lookahead, int blocks_per_xcd, int max_polls, float* sink,
-                                                              long long* dbg) {
-    __shared__ int s_rank;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mode = max_polls >> 24;   // experiment switch (T3MI_PF_MODE): 1 exit at once, 2 sleep ~1 ms, 3 poll but never load
-    max_polls &= 0xFFFFFF;
-    if (mode == 1) return;
-    if (mode == 2) {
-        for (int q = 0; q < 1500; ++q) __builtin_amdgcn_s_sleep(25);
-        return;
-    }
-    const int xcc = hw_xcc_id();
-    if (tid == 0) s_rank = (int)((unsigned)atomicAdd(&state[kPfTickets + xcc], 1) % (unsigned)blocks_per_xcd);
-    __syncthreads();
-    const int rank = s_rank;
-    const int slot = state[kPfSlots + xcc];   // blockIdx % 8 of the chain's blocks that run on this XCD
-    if (slot < 0) return;
-    const int* progress = state + kPfProgress;
-    const int nworkers = blocks_per_xcd * 4, worker = rank * 4 + wave;
-    float acc = 0.f;
-    for (int i = 0; i < n_items; ++i) {
-        const PfItem it = plan[i];
-        if (it.W == nullptr) continue;
-        // throttle: item i is launch number base + i + 1 of the chain; start once launch (that - lookahead) has begun
-        const int mine = base + i + 1;
-        int p = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int polls = 0;
-        while (p < mine - lookahead) {
-            if (++polls > max_polls) goto out;   // the chain is not running (host stalled): give up, every wave exits
-            __builtin_amdgcn_s_sleep(20);
-            p = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (dbg != nullptr && blockIdx.x == 0 && tid == 0) {
-            dbg[4 * i + 0] = p - mine;
-            dbg[4 * i + 1] = (long long)wall_clock64();
-        }
-        if (p > mine || mode == 3) continue;     // that launch has already finished
-        {
-            // all index math in shifts: rows per chunk, chunks per block pass and lines per row are powers of two
-            const int lpr = (int)(it.row_bytes >> 7);                 // 128-byte lines per row
-            const int nb = (it.grid - slot + 7) / 8;                  // consuming blocks on this XCD
-            if (nb <= 0 || lpr <= 0 || (lpr & (lpr - 1)) || (it.rows & (it.rows - 1)) || (it.ngrp & (it.ngrp - 1))) continue;
-            const int lg_lpr = __builtin_ctz(lpr), lg_rows = __builtin_ctz(it.rows), lg_ngrp = __builtin_ctz(it.ngrp);
-            const int lg_lpu = lg_lpr + lg_rows + lg_ngrp;            // lines of one block pass of the consuming launch
-            const int hp = it.rows >> 1, lg_hp = hp > 0 ? __builtin_ctz(hp) : 0;
-            const int passes = (it.n_chunks + it.grid * it.ngrp - 1) / (it.grid * it.ngrp);
-            const int total_lines = (passes * nb) << lg_lpu;
-            const int n_wl = (total_lines + 63) >> 6;
-            const char* Wb = static_cast<const char*>(it.W);
-            for (int wl0 = worker; wl0 < n_wl; wl0 += nworkers * kPfUnroll) {
-                float v[kPfUnroll];
-#pragma unroll
-                for (int uu = 0; uu < kPfUnroll; ++uu) {
-                    v[uu] = 0.f;
-                    const int line = (wl0 + uu * nworkers) * 64 + lane;
-                    if (line < total_lines) {
-                        const unsigned unit = (unsigned)line >> lg_lpu;
-                        const int l = line & ((1 << lg_lpu) - 1);
-                        const unsigned pass = unit / (unsigned)nb, bl = unit - pass * (unsigned)nb;
-                        const int blk = slot + 8 * (int)bl;
-                        const int c = ((blk + (int)pass * it.grid) << lg_ngrp) + (l >> (lg_lpr + lg_rows));
-                        const int j = (l >> lg_lpr) & (it.rows - 1);
-                        if (c < it.n_chunks) {
-                            int row;
-                            if (it.kind == 1) {            // rotate_half pairs of one head (chunk_row<EPI_ROPE_KV>)
-                                const int lg_ph = 5 - lg_hp;
-                                row = ((c >> lg_ph) << 6) + ((c & ((1 << lg_ph) - 1)) << lg_hp) + (j & (hp - 1)) + ((j >> lg_hp) << 5);
-                            } else if (it.kind == 2) {     // gate rows and the matching up rows (chunk_row<EPI_SWIGLU>)
-                                row = (j >> lg_hp) * (it.N >> 1) + (c << lg_hp) + (j & (hp - 1));
-                            } else {
-                                row = (c << lg_rows) + j;
-                            }
-                            if (row < it.N)
-                                v[uu] = *reinterpret_cast<const float*>(Wb + (size_t)row * it.row_bytes + ((size_t)(l & (lpr - 1)) << 7));
-                        }
-                    }
-                }
-#pragma unroll
-                for (int uu = 0; uu < kPfUnroll; ++uu) acc += v[uu];
-            }
-        }
-        if (dbg != nullptr && blockIdx.x == 0 && tid == 0) {
-            asm volatile("" : "+v"(acc));
-            dbg[4 * i + 2] = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mine;
-            dbg[4 * i + 3] = (long long)wall_clock64();
-        }
-    }
-out:
-    if (acc == 123.4567f) sink[blockIdx.x] = acc;   // keeps the loads alive
-}
-
 template <typename WT, int R, int NK, int KSPLIT, int ROWS, int EPI, int PRO>
 hipError_t launch_gemv_t(const GemvArgs& a, hipStream_t s) {
     constexpr int K = NK * kWave * WT::E * KSPLIT;
@@ -1330,25 +1118,6 @@ hipError_t launch_gemv_t(const GemvArgs& a, hipStream_t s) {
     int grid = (n_chunks + per_block - 1) / per_block;
     if (grid > 256 * 8) grid = 256 * 8;
     const size_t lds = ((PRO != PRO_PLAIN ? (size_t)R * K : 0) + (size_t)nw * (ROWS < 2 ? 2 : ROWS) * R + 32) * sizeof(float);
-    if (a.geom_out != nullptr) {
-        PfItem& g = *a.geom_out;
-        g.W = a.W;
-        g.row_bytes = (unsigned)(K * (16 / WT::E));
-        g.N = a.N;
-        g.kind = EPI == EPI_ROPE_KV ? 1 : (EPI == EPI_SWIGLU ? 2 : 0);
-        g.rows = ROWS;
-        g.ngrp = per_block;
-        g.grid = grid;
-        g.n_chunks = n_chunks;
-    }
-    if (a.geom_only) return hipSuccess;
-    for (int jb = 0; jb < 2; ++jb) {   // the in-kernel prefetch does its index math in shifts
-        const PfItem& it = a.pf[jb].item;
-        const int lpr = (int)(it.row_bytes >> 7);
-        if (it.W != nullptr && (lpr <= 0 || (lpr & (lpr - 1)) || it.rows <= 0 || (it.rows & (it.rows - 1)) || it.ngrp <= 0 ||
-                                (it.ngrp & (it.ngrp - 1)) || it.grid <= 0))
-            return hipErrorInvalidValue;
-    }
     auto kfn = gemv_kernel<WT, R, NK, KSPLIT, ROWS, EPI, PRO>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -1478,28 +1247,6 @@ hipError_t launch_sampler(const SamplerArgs& a, hipStream_t s) {
     const size_t lds = sampler_lds_bytes(a.V);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sampler_kernel, dim3(a.n_utt), dim3(kSampThreads), lds, s, a, npad);
-    return hipGetLastError();
-}
-
-hipError_t launch_xcc_census(int* out, hipStream_t s) {
-    hipLaunchKernelGGL(xcc_census_kernel, dim3(256), dim3(256), 0, s, out);
-    return hipGetLastError();
-}
-
-hipError_t launch_weight_prefetch(const PfItem* plan_dev, int n_items, int* state, int base, int lookahead, int blocks,
-                                  int depth, int max_polls, float* sink, hipStream_t s, long long* dbg) {
-    if (plan_dev == nullptr || state == nullptr || n_items <= 0 || blocks < 8 || (blocks % 8)) return hipErrorInvalidValue;
-#define T3K_PF_LAUNCH(U)                                                                                              \
-    hipLaunchKernelGGL(weight_prefetch_kernel<U>, dim3(blocks), dim3(256), 0, s, plan_dev, n_items, state, base, lookahead, \
-                       blocks / 8, max_polls, sink, dbg)
-    switch (depth) {
-        case 1: T3K_PF_LAUNCH(1); break;
-        case 2: T3K_PF_LAUNCH(2); break;
-        case 4: T3K_PF_LAUNCH(4); break;
-        case 8: T3K_PF_LAUNCH(8); break;
-        default: return hipErrorInvalidValue;
-    }
-#undef T3K_PF_LAUNCH
     return hipGetLastError();
 }
 

@@ -26,26 +26,6 @@ enum Prologue : int {
 #define T3K_STAMP_WAVES 8192
 #endif
 
-// One weight-streaming launch of the decode step as the L2 prefetcher sees it (weight_prefetch_kernel):
-// which rows of W the blocks of each XCD will stream.  Filled by launch_gemv (geom_out).
-struct PfItem {
-    const void* W = nullptr;      // nullptr: a launch that streams no weights (sampler, attention)
-    unsigned row_bytes = 0;       // K * sizeof(weight element)
-    int N = 0;                    // rows of W
-    int kind = 0;                 // chunk -> row map: 0 linear, 1 rotate_half pairs (QKV), 2 gate/up pairs
-    int rows = 1;                 // rows per chunk
-    int ngrp = 1;                 // chunks a block handles per pass
-    int grid = 1;                 // blocks of the launch
-    int n_chunks = 0;
-};
-
-// In-kernel L2 prefetch job: this launch touches wave-loads [n * begin16 / 16, n * end16 / 16) of `item`, the weight
-// matrix of a LATER launch of the chain (n = 8 KB wave-loads of the item on one XCD).
-struct PfJob {
-    PfItem item;
-    int begin16 = 0, end16 = 0;
-};
-
 struct GemvArgs {
     const void* W = nullptr;      // [N, K] row-major (row = output feature), fp32 or bf16
     const float* x = nullptr;     // [rows, K]
@@ -72,10 +52,6 @@ struct GemvArgs {
     int n_split_max = 0, keys_per_split = 0;
     int waves = 0;                // waves per block (0 = default 4)
     int rows_per_chunk = 0;       // output features per wave-chunk (0 = kernel default)
-    int* progress = nullptr;      // device launch counter of the decode chain (block 0 adds 1), or nullptr
-    PfItem* geom_out = nullptr;   // host: receives this launch's geometry for the prefetch plan
-    int geom_only = 0;            // host: 1 = report the geometry, launch nothing (plan dry run)
-    PfJob pf[2];                  // weights of later launches to pull into this XCD's L2 (item.W == nullptr: none)
 #ifdef T3K_STAMPS
     unsigned long long* stamps = nullptr;  // diagnostic build only: [T3K_STAMP_WAVES][T3K_STAMP_SLOTS] of this launch
 #endif
@@ -92,7 +68,6 @@ struct AttnArgs {
     float* pacc = nullptr;
     int rows = 0, n_heads = 0, max_len = 0;
     int n_split_max = 0, keys_per_split = 64;
-    int* progress = nullptr;
 #ifdef T3K_STAMPS
     unsigned long long* stamps = nullptr;
 #endif
@@ -165,7 +140,6 @@ struct SamplerArgs {
     int* dist_n = nullptr;
     int* drawn = nullptr;         // [n_utt] token drawn before teacher forcing (debug)
     int dist_cap = 0;
-    int* progress = nullptr;
 };
 
 size_t sampler_lds_bytes(int V);
@@ -186,8 +160,6 @@ hipError_t launch_layernorm_rows(float* x, const float* w, const float* b, float
 hipError_t launch_rmsnorm_rows(float* x, const float* w, float eps, void* out, int M, int d, int act_bf16, hipStream_t s,
                                const float* part = nullptr, int ks = 0, const float* pbias = nullptr);
 hipError_t launch_fold_partials(float* x, const float* part, int ks, const float* pbias, int M, int d, hipStream_t s);
-hipError_t launch_attn_merge(const float* pm, const float* pl, const float* pacc, const int* posmap, void* out, int M,
-                             int H, int n_split_max, int kps, int act_bf16, hipStream_t s);
 // many-row attention (batched decode, prefill): one block per (query item, head) over keys 0..posmap[item]; writes
 // the normalised output rows in the activation type of the o_proj GEMM.  kv_bf16 / out_bf16: element types.
 struct AttnRowsArgs {
@@ -201,16 +173,6 @@ struct AttnRowsArgs {
 };
 hipError_t launch_attn_rows(const AttnRowsArgs& a, hipStream_t s);
 hipError_t launch_gather_rows(const float* const* src_rows, float* x, int M, int d, hipStream_t s);
-// ---- L2 weight prefetcher (runs beside the decode chain on its own stream; performance hint only) ----
-// state: int[32] device words: [0] progress counter, [8..15] per-XCD tickets, [16..23] slot_of_xcc
-//        [24] diagnostic switch, [32..1055] XCD of block 0 of the last 1024 chain launches
-constexpr int kPfProgress = 0, kPfTickets = 8, kPfSlots = 16, kPfLogOn = 24, kPfXccLog = 32, kPfWords = 32 + 1024;
-// records the hardware XCD id of every block of a 256-block launch into out[256] (placement census)
-hipError_t launch_xcc_census(int* out, hipStream_t s);
-// prefetches the weights of plan items [0, n_items) of the step whose first launch is number `base`
-hipError_t launch_weight_prefetch(const PfItem* plan_dev, int n_items, int* state, int base, int lookahead,
-                                  int blocks, int depth, int max_polls, float* sink, hipStream_t s,
-                                  long long* dbg = nullptr);
 // ---- prompt builder (prompt_kernels.hip; R/t3.R:48-90, 161-195, 278-315, 372-403) ----
 // out[r] = table[ids[r]] (+ pos[r]), r < n; ids on device, checked against the table size by the caller
 hipError_t launch_embed_rows(const float* table, const int* ids, const float* pos, float* out, int n, int d, hipStream_t s);

@@ -9,7 +9,6 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
-#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -91,17 +90,6 @@ struct Session {
     DevBuf kc, vc, x, qbuf, pm, pl, pacc, hbuf, logits, rope_cur, rowpos, start, emb_rows, emb_data, seen, tokens, n_tokens,
         done, s0_dev, forced, dist_ids, dist_probs, dist_n, drawn;
     int n_forced = 0;
-    // L2 weight prefetcher (see weight_prefetch_kernel): the step's weight-streaming launches in order
-    // in-kernel prefetch (GemvArgs::pf): each weight-streaming launch of the step pulls the weights of the next
-    // ones into L2; jobs[i] belongs to launch i of the step (same order as plan)
-    bool ikpf = false, jobs_ready = false, dry = false, in_step = false;
-    int li = 0;
-    std::vector<std::array<t3k::PfJob, 2>> jobs;
-    bool pf_on = false, plan_ready = false, plan_collect = false;
-    std::vector<t3k::PfItem> plan;
-    DevBuf plan_dev, pf_dbg;   // pf_dbg: T3MI_PF_DEBUG=1 diagnostic (per item: counter lead and clock at start / end)
-    long long bumps = 0;   // host mirror of the device launch counter
-    int step_bumps = 0;    // launches of one decode step
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     bool graph_tried = false;
@@ -131,13 +119,6 @@ struct t3mi_model {
     t3mi::PromptModel* prompt = nullptr;   // text_emb / cond_enc.* tensors (nullptr: decode-only checkpoint)
     DevBuf prompt_buf;                     // prompts built on device, alive until the next build
     bool use_graph = true;
-    hipStream_t pf_stream = nullptr;   // the prefetcher runs beside the decode chain
-    DevBuf pf_state, pf_sink;
-    bool pf_ok = false;                // placement census passed and T3MI_PREFETCH != 0
-    bool ikpf_ok = false;              // in-kernel L2 prefetch: experiment, T3MI_IKPF=1 turns it on (the consumer
-                                       // gains 1.5-1.8 us, the prefetching launch pays 2.6-3.3 us: HBM time only moves)
-    int ikpf_split16 = 8, ikpf_big_mb = 24;   // big items are shared with the launch before: its share in 1/16, threshold
-    int pf_lookahead = 2, pf_blocks = 64, pf_depth = 2, pf_max_polls = 4000;
     int tune[5] = {8, 4, 8, 8, 8};  // waves per block: qkv, o_proj, gate_up, down, head (T3MI_WAVES=a,b,c,d,e)
     int tune_rows[5] = {2, 1, 2, 2, 2};  // output rows per wave-chunk, same order (T3MI_ROWS=a,b,c,d,e)
 };
@@ -336,15 +317,6 @@ int load_llama(t3mi_model* m, const t3mi::SafeTensorsFile& st) {
         if ((rc = up.put_w(p + "mlp.down_proj.weight", d, F, w))) return rc;
         w += d * F * es;
     }
-    if (const char* al = std::getenv("T3MI_DEBUG_ALIAS_LAYERS")) {
-        // measurement aid only (results are wrong): every layer streams layer 0's weights, so the
-        // whole working set stays in the 256 MiB Infinity Cache -- the chain's speed without HBM
-        if (al[0] == '1')
-            for (int l = 1; l < L; ++l) {
-                m->layers[l].wqkv = m->layers[0].wqkv; m->layers[l].wo = m->layers[0].wo;
-                m->layers[l].wgu = m->layers[0].wgu; m->layers[l].wdown = m->layers[0].wdown;
-            }
-    }
     m->norm_w = sm;
     if ((rc = up.put_f32("tfmr.norm.weight", d, -1, sm))) return rc;
     m->head_w = w;
@@ -465,25 +437,6 @@ unsigned long long* next_stamps() {
 #define T3MI_SET_STAMPS(a) do { } while (0)
 #endif
 
-// chain launch bookkeeping for the prefetcher: counter pointer into the kernel, geometry into the plan
-inline int* pf_progress(t3mi_model* m, Session* s) {
-    if (!s->pf_on) return nullptr;
-    s->bumps += 1;
-    return m->pf_state.as<int>() + t3k::kPfProgress;
-}
-inline void pf_note(Session* s, const t3k::PfItem& it) {
-    if ((s->pf_on || s->ikpf) && s->plan_collect) s->plan.push_back(it);
-}
-// launch index within the decode step (-1 outside a step) and that launch's prefetch jobs
-inline int step_launch_index(Session* s) { return s->in_step ? s->li++ : -1; }
-inline void pf_jobs(Session* s, int li, t3k::GemvArgs& a) {
-    a.geom_only = s->dry ? 1 : 0;
-    if (s->jobs_ready && li >= 0 && li < (int)s->jobs.size()) {
-        a.pf[0] = s->jobs[li][0];
-        a.pf[1] = s->jobs[li][1];
-    }
-}
-
 struct StepTimer {  // optional per-launch events for t3mi_session_profile_step
     std::vector<hipEvent_t> ev;
     std::vector<int> kind;
@@ -524,12 +477,8 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.n_heads = H; a.max_len = s->max_len;
             a.waves = m->tune[0]; a.rows_per_chunk = m->tune_rows[0];
             if (turbo) { a.layernorm = 1; a.bias = lw.b_qkv_f; a.rope = 0; }
-            t3k::PfItem geom;
-            a.progress = pf_progress(m, s); a.geom_out = &geom;
             T3MI_SET_STAMPS(a);
-            pf_jobs(s, step_launch_index(s), a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_ROPE_KV, m->wdtype, m->stream));
-            pf_note(s, geom);
             r0 += rg;
         }
         if (tm) tm->mark(K_QKV);
@@ -540,11 +489,8 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.pm = s->pm.as<float>(); a.pl = s->pl.as<float>(); a.pacc = s->pacc.as<float>();
             a.rows = s->rows; a.n_heads = H; a.max_len = s->max_len;
             a.n_split_max = s->n_split; a.keys_per_split = s->kps;
-            a.progress = pf_progress(m, s);
-            (void)step_launch_index(s);
             T3MI_SET_STAMPS(a);
-            if (!s->dry) HIPCHK(t3k::launch_attn_decode(a, m->stream));
-            pf_note(s, t3k::PfItem{});
+            HIPCHK(t3k::launch_attn_decode(a, m->stream));
         }
         if (tm) tm->mark(K_ATTN);
         // K3: softmax-merge + o_proj + residual
@@ -560,12 +506,8 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
             a.waves = m->tune[1]; a.rows_per_chunk = m->tune_rows[1];
             a.bias = lw.b_o;
-            t3k::PfItem geom;
-            a.progress = pf_progress(m, s); a.geom_out = &geom;
             T3MI_SET_STAMPS(a);
-            pf_jobs(s, step_launch_index(s), a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
-            pf_note(s, geom);
             r0 += rg;
         }
         if (tm) tm->mark(K_OPROJ);
@@ -578,12 +520,8 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.y = s->hbuf.as<float>() + (size_t)r0 * F; a.ldy = F;
             a.waves = m->tune[2]; a.rows_per_chunk = m->tune_rows[2];
             if (turbo) { a.layernorm = 1; a.bias = lw.b_fc_f; }   // LayerNorm + c_fc + gelu_tanh (R/t3.R:1303-1304)
-            t3k::PfItem geom;
-            a.progress = pf_progress(m, s); a.geom_out = &geom;
             T3MI_SET_STAMPS(a);
-            pf_jobs(s, step_launch_index(s), a);
             HIPCHK(t3k::launch_gemv(a, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, m->wdtype, m->stream));
-            pf_note(s, geom);
             r0 += rg;
         }
         if (tm) tm->mark(K_GATEUP);
@@ -595,12 +533,8 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
             a.waves = m->tune[3]; a.rows_per_chunk = m->tune_rows[3];
             a.bias = lw.b_down;
-            t3k::PfItem geom;
-            a.progress = pf_progress(m, s); a.geom_out = &geom;
             T3MI_SET_STAMPS(a);
-            pf_jobs(s, step_launch_index(s), a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_RESID, m->wdtype, m->stream));
-            pf_note(s, geom);
             r0 += rg;
         }
         if (tm) tm->mark(K_DOWN);
@@ -743,12 +677,8 @@ int run_head(t3mi_model* m, Session* s, StepTimer* tm) {
         a.y = s->logits.as<float>() + (size_t)r0 * m->V; a.ldy = m->V;
         a.waves = m->tune[4]; a.rows_per_chunk = m->tune_rows[4];
         if (turbo) { a.layernorm = 1; a.bias = m->head_b_f; }   // ln_f + speech_head with bias (R/t3.R:1444)
-        t3k::PfItem geom;
-        a.progress = pf_progress(m, s); a.geom_out = &geom;
         T3MI_SET_STAMPS(a);
-        pf_jobs(s, step_launch_index(s), a);
             HIPCHK(t3k::launch_gemv(a, t3k::EPI_STORE, m->wdtype, m->stream));
-        pf_note(s, geom);
         r0 += rg;
     }
     if (tm) tm->mark(K_HEAD);
@@ -774,18 +704,13 @@ int run_sampler(t3mi_model* m, Session* s, StepTimer* tm) {
     a.dist_ids = s->dist_ids.as<int>(); a.dist_probs = s->dist_probs.as<float>(); a.dist_n = s->dist_n.as<int>();
     a.drawn = s->drawn.as<int>();
     a.dist_cap = m->V;
-    a.progress = pf_progress(m, s);
-    (void)step_launch_index(s);
-    if (!s->dry) HIPCHK(t3k::launch_sampler(a, m->stream));
-    pf_note(s, t3k::PfItem{});
+    HIPCHK(t3k::launch_sampler(a, m->stream));
     if (tm) tm->mark(K_SAMPLER);
     return T3MI_OK;
 }
 
 int run_decode_step(t3mi_model* m, Session* s, StepTimer* tm) {
     int rc;
-    s->li = 0;
-    s->in_step = true;
     if (!(rc = run_sampler(m, s, tm))) {
         if (s->gemm_mode) {
             GemmCtx c = decode_ctx(s);
@@ -796,88 +721,13 @@ int run_decode_step(t3mi_model* m, Session* s, StepTimer* tm) {
         else rc = run_layers(m, s, tm);
     }
     if (!rc) rc = run_head(m, s, tm);
-    s->in_step = false;
     return rc;
-}
-
-// Prefetch plan of the in-kernel L2 prefetch: a dry pass over one decode step records every launch's geometry, then
-// every weight matrix is assigned to the weight-streaming launch before it (wrapping: the head prefetches layer 0's
-// QKV weights of the next step).  Matrices above ikpf_big_mb are shared with the streaming launch before that one.
-int plan_ikpf(t3mi_model* m, Session* s) {
-    if (!s->ikpf || s->jobs_ready) return T3MI_OK;
-    const long long bumps0 = s->bumps;
-    s->plan.clear();
-    s->plan_collect = true;
-    s->dry = true;
-    int rc = run_decode_step(m, s, nullptr);
-    s->dry = false;
-    s->plan_collect = false;
-    s->bumps = bumps0;
-    if (rc) return rc;
-    const int n = (int)s->plan.size();
-    s->jobs.assign(n, {});
-    std::vector<int> streaming;
-    for (int i = 0; i < n; ++i)
-        if (s->plan[i].W != nullptr) streaming.push_back(i);
-    const int ns = (int)streaming.size();
-    auto add_job = [&](int launch, const t3k::PfItem& it, int b16, int e16) {
-        for (auto& j : s->jobs[launch])
-            if (j.item.W == nullptr) {
-                j.item = it;
-                j.begin16 = b16;
-                j.end16 = e16;
-                return;
-            }
-    };
-    for (int k = 0; k < ns && ns >= 3; ++k) {
-        const t3k::PfItem& it = s->plan[streaming[k]];
-        const int p1 = streaming[(k + ns - 1) % ns], p2 = streaming[(k + ns - 2) % ns];
-        const double mb = (double)it.N * it.row_bytes / 1e6;
-        if (const char* v = std::getenv("T3MI_IKPF_MIN_MB")) if (mb < std::atof(v)) continue;   // experiments
-        if (const char* v = std::getenv("T3MI_IKPF_MAX_MB")) if (mb > std::atof(v)) continue;
-        if (mb > m->ikpf_big_mb && m->ikpf_split16 > 0) {
-            add_job(p2, it, 0, m->ikpf_split16);
-            add_job(p1, it, m->ikpf_split16, 16);
-        } else {
-            add_job(p1, it, 0, 16);
-        }
-    }
-    s->jobs_ready = true;
-    return T3MI_OK;
-}
-
-int upload_plan(t3mi_model* m, Session* s) {
-    if (!s->pf_on || s->plan_ready || s->plan.empty()) return T3MI_OK;
-    HIPCHK(s->plan_dev.alloc(s->plan.size() * sizeof(t3k::PfItem)));
-    HIPCHK(hipMemcpy(s->plan_dev.p, s->plan.data(), s->plan.size() * sizeof(t3k::PfItem), hipMemcpyHostToDevice));
-    s->plan_ready = true;
-    if (const char* d = std::getenv("T3MI_PF_DEBUG"))
-        if (d[0] == '1') {
-            HIPCHK(s->pf_dbg.alloc(s->plan.size() * 4 * 8));
-            HIPCHK(hipMemset(s->pf_dbg.p, 0, s->plan.size() * 4 * 8));
-        }
-    return T3MI_OK;
-}
-
-// enqueue the prefetcher of the step whose first launch will be number s->bumps + 1
-int launch_prefetch(t3mi_model* m, Session* s) {
-    if (!s->pf_on || !s->plan_ready) return T3MI_OK;
-    HIPCHK(t3k::launch_weight_prefetch(s->plan_dev.as<t3k::PfItem>(), (int)s->plan.size(), m->pf_state.as<int>(),
-                                       (int)s->bumps, m->pf_lookahead, m->pf_blocks, m->pf_depth, m->pf_max_polls,
-                                       m->pf_sink.as<float>(), m->pf_stream, s->pf_dbg.as<long long>()));
-    return T3MI_OK;
 }
 
 int build_graph(t3mi_model* m, Session* s) {
     s->graph_tried = true;
-    const long long bumps0 = s->bumps;
-    s->plan_collect = s->pf_on && !s->plan_ready;
-    if (s->plan_collect) s->plan.clear();
     HIPCHK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
     int rc = run_decode_step(m, s, nullptr);
-    s->plan_collect = false;
-    s->step_bumps = (int)(s->bumps - bumps0);
-    s->bumps = bumps0;   // captured, not executed
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(m->stream, &g);
     if (rc) {
@@ -887,7 +737,7 @@ int build_graph(t3mi_model* m, Session* s) {
     if (e != hipSuccess) return fail(T3MI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
     s->graph = g;
     HIPCHK(hipGraphInstantiate(&s->gexec, g, nullptr, nullptr, 0));
-    return upload_plan(m, s);
+    return T3MI_OK;
 }
 
 int need_session(t3mi_model* m) {
@@ -956,60 +806,9 @@ int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model*
     }
     HIPCHK(t3k::init_device());
     HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&m->pf_stream, hipStreamNonBlocking));
-    {
-        // block placement census: the prefetcher needs "blocks with blockIdx % 8 == k run on hardware XCD q"
-        HIPCHK(m->pf_state.alloc(t3k::kPfWords * 4));
-        HIPCHK(m->pf_sink.alloc(1024 * 4));
-        DevBuf cen;
-        HIPCHK(cen.alloc(256 * 4));
-        HIPCHK(t3k::launch_xcc_census(cen.as<int>(), m->stream));
-        HIPCHK(hipStreamSynchronize(m->stream));
-        int xcc[256];
-        std::vector<int> stv(t3k::kPfWords, 0);
-        int* st = stv.data();
-        HIPCHK(hipMemcpy(xcc, cen.p, sizeof(xcc), hipMemcpyDeviceToHost));
-        if (const char* d = std::getenv("T3MI_PF_DEBUG")) st[t3k::kPfLogOn] = d[0] == '1';
-        for (int q = 0; q < 8; ++q) st[t3k::kPfSlots + q] = -1;
-        bool ok = true;
-        int cnt[8] = {0};
-        for (int b = 0; b < 256 && ok; ++b) {
-            const int q = xcc[b];
-            if (q < 0 || q > 7) { ok = false; break; }
-            int& slot = st[t3k::kPfSlots + q];
-            if (slot < 0) slot = b % 8;
-            else if (slot != b % 8) ok = false;
-            cnt[q] += 1;
-        }
-        for (int q = 0; q < 8; ++q) ok = ok && cnt[q] == 32;
-        const char* pe = std::getenv("T3MI_PREFETCH");
-        m->pf_ok = ok && pe && pe[0] == '1';   // experiment, off by default: measured slower
-#ifndef T3K_PREFETCH_EXPERIMENTS
-        m->pf_ok = false;                      // the kernels carry the hooks only in a -DT3K_PREFETCH_EXPERIMENTS build
-#endif
-        HIPCHK(hipMemcpy(m->pf_state.p, st, stv.size() * 4, hipMemcpyHostToDevice));
-        if (const char* v = std::getenv("T3MI_PF_LOOKAHEAD")) m->pf_lookahead = std::max(1, std::atoi(v));
-        if (const char* v = std::getenv("T3MI_IKPF")) m->ikpf_ok = v[0] == '1';
-        m->ikpf_ok = m->ikpf_ok && ok;   // needs the same block -> XCD placement in every launch
-#ifndef T3K_PREFETCH_EXPERIMENTS
-        m->ikpf_ok = false;
-#endif
-        if (const char* v = std::getenv("T3MI_IKPF_SPLIT")) m->ikpf_split16 = std::min(16, std::max(0, std::atoi(v)));
-        if (const char* v = std::getenv("T3MI_IKPF_BIG_MB")) m->ikpf_big_mb = std::max(1, std::atoi(v));
-        if (const char* v = std::getenv("T3MI_PF_MODE")) m->pf_max_polls |= (std::atoi(v) & 3) << 24;
-        if (const char* v = std::getenv("T3MI_PF_DEPTH")) {
-            const int dp = std::atoi(v);
-            if (dp == 1 || dp == 2 || dp == 4 || dp == 8) m->pf_depth = dp;
-        }
-        if (const char* v = std::getenv("T3MI_PF_BLOCKS")) {
-            const int nb = std::atoi(v);
-            if (nb >= 8 && nb <= 1024 && nb % 8 == 0) m->pf_blocks = nb;
-        }
-    }
     int rc = variant == T3MI_VARIANT_TURBO ? load_turbo(m.get(), st) : load_llama(m.get(), st);
     if (rc) {
         (void)hipStreamDestroy(m->stream);
-        (void)hipStreamDestroy(m->pf_stream);
         return rc;
     }
     {
@@ -1017,13 +816,11 @@ int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model*
         const int prc = t3mi::prompt_load(st, variant, m->d, &m->prompt, perr);
         if (prc < 0) {
             (void)hipStreamDestroy(m->stream);
-            (void)hipStreamDestroy(m->pf_stream);
-            return fail(prc, perr);
+                return fail(prc, perr);
         }
     }
     if (t3k::sampler_lds_bytes(m->V) > 160 * 1024 || m->V > 16384) {
         (void)hipStreamDestroy(m->stream);
-        (void)hipStreamDestroy(m->pf_stream);
         return fail(T3MI_ERR_IO, "vocabulary too large for the single-workgroup sampler");
     }
     HIPCHK(hipDeviceSynchronize());
@@ -1035,12 +832,10 @@ int t3mi_close(t3mi_model* m) {
     if (!m) return T3MI_OK;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    if (m->pf_stream) (void)hipStreamSynchronize(m->pf_stream);
     m->sess.reset();
     t3mi::prompt_free(m->prompt);
     m->prompt = nullptr;
     if (m->stream) (void)hipStreamDestroy(m->stream);
-    if (m->pf_stream) (void)hipStreamDestroy(m->pf_stream);
     delete m;
     return T3MI_OK;
 }
@@ -1067,21 +862,6 @@ int t3mi_session_end(t3mi_model* m) {
     if (!m) return fail(T3MI_ERR_ARG, "null model handle");
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    if (m->pf_stream) (void)hipStreamSynchronize(m->pf_stream);
-    if (m->sess && m->sess->pf_dbg.p) {
-        std::vector<int> lg(1024);
-        if (hipMemcpy(lg.data(), m->pf_state.as<int>() + t3k::kPfXccLog, 4096, hipMemcpyDeviceToHost) == hipSuccess) {
-            std::fprintf(stderr, "xcd of block 0, last launches:");
-            const long long n = m->sess->bumps;
-            for (long long i = std::max(0LL, n - 160); i < n; ++i) std::fprintf(stderr, " %d", lg[i & 1023]);
-            std::fprintf(stderr, "\n");
-        }
-        std::vector<long long> h(m->sess->plan.size() * 4);
-        if (hipMemcpy(h.data(), m->sess->pf_dbg.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
-            for (size_t i = 0; i < m->sess->plan.size() && i < 24; ++i)
-                std::fprintf(stderr, "pf item %2zu: lead at start %lld, at end %lld, t_start %.2f us, busy %.2f us\n", i, -h[4 * i],
-                             -h[4 * i + 2], (double)(h[4 * i + 1] - h[1]) * 0.01, (double)(h[4 * i + 3] - h[4 * i + 1]) * 0.01);
-    }
     m->sess.reset();
     return T3MI_OK;
 }
@@ -1146,8 +926,7 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         const int thr = gm ? std::atoi(gm) : 4;
         s->gemm_mode = (int)rows > thr;
         const char* kve = std::getenv("T3MI_KV");        // "f32" keeps fp32 KV slabs in the many-row bf16 regime
-        const char* g1 = std::getenv("T3MI_GEMM_GEN1");
-        s->kv_bf16 = s->gemm_mode && m->wdtype == T3MI_W_BF16 && d % 256 == 0 && !(kve && kve[0] == 'f') && !(g1 && g1[0] == '1');
+        s->kv_bf16 = s->gemm_mode && m->wdtype == T3MI_W_BF16 && d % 256 == 0 && !(kve && kve[0] == 'f');
     }
     const size_t kv = (size_t)m->n_layers * rows * m->H * s->max_len * 64 * (s->kv_bf16 ? 2 : 4);
     HIPCHK(s->kc.alloc(kv));
@@ -1173,9 +952,6 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         const size_t part_rows = std::max<size_t>(s->gemm_mode ? rows : 0, items <= 1024 ? items : 0);
         HIPCHK(s->gpart.alloc(part_rows ? 8 * part_rows * d * 4 : 16));
     }
-    s->pf_on = m->pf_ok && !s->gemm_mode && rows <= 4;
-    s->ikpf = m->ikpf_ok && !s->pf_on && !s->gemm_mode && rows <= 4;
-    if (s->pf_on) HIPCHK(hipMemsetAsync(m->pf_state.as<int>() + t3k::kPfProgress, 0, 4, m->stream));
     HIPCHK(s->logits.alloc(rows * V * 4));
     HIPCHK(s->rowpos.alloc(rows * 4));
     HIPCHK(s->rope_cur.alloc(rows * 128 * 4));
@@ -1336,23 +1112,12 @@ int t3mi_session_decode(t3mi_model* m, int n_steps) {
     if (n_steps <= 0) return fail(T3MI_ERR_ARG, "n_steps must be positive");
     Session* s = m->sess.get();
     HIPCHK(hipSetDevice(m->device));
-    if ((rc = plan_ikpf(m, s))) return rc;
     if (m->use_graph && !s->graph_tried) {
         if ((rc = build_graph(m, s))) return rc;
     }
     for (int i = 0; i < n_steps; ++i) {
-        if ((rc = launch_prefetch(m, s))) return rc;
-        if (s->gexec) {
-            HIPCHK(hipGraphLaunch(s->gexec, m->stream));
-            s->bumps += s->step_bumps;
-        } else {
-            s->plan_collect = s->pf_on && !s->plan_ready;
-            if (s->plan_collect) s->plan.clear();
-            rc = run_decode_step(m, s, nullptr);
-            s->plan_collect = false;
-            if (rc) return rc;
-            if ((rc = upload_plan(m, s))) return rc;
-        }
+        if (s->gexec) HIPCHK(hipGraphLaunch(s->gexec, m->stream));
+        else if ((rc = run_decode_step(m, s, nullptr))) return rc;
     }
     return T3MI_OK;
 }
@@ -1467,9 +1232,7 @@ int t3mi_session_profile_step(t3mi_model* m, t3mi_kstat* stats, int cap, int* n_
     StepTimer tm;
     tm.s = m->stream;
     tm.on = true;
-    if ((rc = plan_ikpf(m, s))) return rc;
     tm.mark(-1);
-    if (!s->plan_collect) (void)launch_prefetch(m, s);
     rc = run_decode_step(m, s, &tm);
     if (!rc) {
         hipError_t e = hipStreamSynchronize(m->stream);
