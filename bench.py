@@ -4,11 +4,23 @@
 A "step" is one decode step of the hot path: sampling tail -> 30 Llama layers -> speech head,
 for every live utterance of the batch (one new speech token per utterance per step).
 
-Workload at N=1 (BASELINE.json configs[1]): ONE utterance with its CFG cond/uncond pair
-(2 activation rows) on one MI355X, greedy (top_p = 0), prompt S0 = 52, stop token masked so
-exactly K steps run, Llama-520M shapes with fp32 weights in the reference's safetensors
-layout (synthetic weights: no checkpoint offline; SURVEY §8d cfg 2).  With --gpus N every
-rank decodes its own utterance (weak scaling, no data-path collective).
+Default workload (BASELINE.json configs[1]): ONE utterance with its CFG cond/uncond pair
+(2 activation rows) per GPU, greedy (top_p = 0), prompt S0 = 52, stop token masked so exactly K
+steps run, Llama-520M shapes with fp32 weights in the reference's safetensors layout (synthetic
+weights: no checkpoint offline; SURVEY §8d cfg 2).  With --gpus N every rank decodes its own
+utterance ("scaling": "weak", no data-path collective).
+
+--total-utterances T (BASELINE.json configs[3], SURVEY §8d cfg 4): T utterances are partitioned
+over the ranks with chatterbox_amd.shard (u -> floor(u*G/T)), every rank decodes its block as one
+batched session and the token vectors are gathered in utterance order ("scaling": "strong").
+
+The rank count is the one the process group actually has: under a launcher (torchrun) WORLD_SIZE
+must equal --gpus or the run exits non-zero; without a launcher the parent process (which makes no
+GPU call) starts --gpus fresh rank processes itself.
+
+The N = 1 default run also attaches, under extra keys of the SAME JSON line, the 64-utterance
+bf16 session of configs[2] ("batch64") and the 512-utterance workload of configs[3] on this
+rank count ("cfg4_512utt"), each measured after the headline region.
 
 Prefill and weight upload happen before the timed region (inputs resident in HBM); the timed
 region is exactly K decode steps bracketed by barrier + synchronize on both sides.
@@ -17,6 +29,8 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,26 +42,76 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--utterances", type=int, default=1, help="utterances per GPU (1 = configs[1])")
-    ap.add_argument("--s0", type=int, default=52)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="weight storage type")
+    ap.add_argument("--utterances", type=int, default=1, help="utterances per GPU (1 = configs[1]); weak scaling")
+    ap.add_argument("--total-utterances", type=int, default=0,
+                    help="> 0: strong scaling, this many utterances partitioned over the ranks (512 = configs[3])")
+    ap.add_argument("--s0", type=int, default=0, help="prompt length (default 52; 64 with --total-utterances)")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
+                    help="weight storage type (default f32; bf16 with --total-utterances)")
     ap.add_argument("--cpu-steps", type=int, default=600, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-attach", action="store_true", help="skip the batch64 / cfg4_512utt attachments")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barriers (gloo: rehearsal of the N > 1 path on a box with fewer GPUs "
                          "than ranks; ranks then share devices round-robin)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ---------------------------------------------------------------------------------------------------------
+# rank bookkeeping (no GPU call in this part)
+
+def resolve_world(gpus: int, env=None):
+    """(world, rank, local_rank, spawn): the rank count this process group really has.  Under a launcher
+    WORLD_SIZE must equal --gpus (raises SystemExit(2) otherwise: a line that says "n_gpus": 8 for a
+    one-rank run would be fabricated scaling).  Without a launcher and --gpus > 1, spawn = True: the parent
+    starts the ranks itself."""
+    env = os.environ if env is None else env
+    if "WORLD_SIZE" not in env:
+        return (1, 0, 0, gpus > 1)
+    world = int(env["WORLD_SIZE"])
+    if world != gpus:
+        sys.stderr.write(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={world} ranks; "
+                         f"refusing to report a rank count that did not run\n")
+        raise SystemExit(2)
+    return (world, int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")), False)
+
+
+def spawn_ranks(gpus: int, argv) -> int:
+    """Parent without a launcher: start `gpus` fresh rank processes of this script (one per GPU), relay rank 0's
+    stdout, return the worst exit code.  The parent never touches the GPU (it does not even import torch)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------
+# workload pieces
 
 def prompt_embeds(s0: int, d: int, seed: int) -> np.ndarray:
     """cfg-2 stand-in: the reference's real prompt activations
     (tests/golden/ref_prompt_embeds.npz, [2,43,1024]) tiled/padded to [2,s0,1024];
-    other utterances get N(0,.53^2) prompts."""
+    other utterances get N(0,.53^2) prompts (seed 1000 + u)."""
     from chatterbox_amd import synth
     g = os.path.join(ROOT, "tests", "golden", "ref_prompt_embeds.npz")
     if seed == 0 and os.path.exists(g) and d == 1024:
@@ -63,6 +127,11 @@ def step_bytes(info, rows: int, L: float, b_w: int, b_kv: int = 4) -> float:
     d, F, V, nl = info.d_model, info.d_ff, info.vocab, info.n_layers
     P = nl * (4 * d * d + 3 * d * F + 2 * d) + d + V * d
     return P * b_w + rows * nl * 2 * d * (L + 1) * b_kv + rows * V * 4
+
+
+def kv_is_bf16(dtype: str, rows: int) -> bool:
+    # the library keeps a bf16 KV cache when bf16 weights meet more than 4 activation rows (DESIGN.md §2)
+    return dtype == "bf16" and rows > 4 and os.environ.get("T3MI_KV", "")[:1] != "f"
 
 
 def cpu_baseline(n_steps: int, s0: int, emb: np.ndarray):
@@ -102,90 +171,205 @@ def cpu_baseline(n_steps: int, s0: int, emb: np.ndarray):
                       f"1 utterance + CFG pair, Llama-520M synthetic weights; {dt:.1f} s of CPU work"}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
-    import torch
-    dist = None
-    if args.backend == "gloo":
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    if world > 1:
-        import torch.distributed as dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist_mod.init_process_group("gloo")
-        dist = dist_mod
-    else:
-        torch.cuda.set_device(local_rank)
+class Ranks:
+    """The process group as this run sees it: barrier, max-over-ranks, and the module for shard.decode_sharded."""
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    def __init__(self, world, rank, local_rank, backend):
+        import torch
+        self.torch, self.world, self.rank, self.backend = torch, world, rank, backend
+        self.dist = None
+        ndev = max(torch.cuda.device_count(), 1)
+        self.local_rank = local_rank % ndev if backend == "gloo" else local_rank
+        self.gpu = torch.cuda.is_available()      # False only in the CPU tests of this file's host logic
+        if self.gpu:
+            torch.cuda.set_device(self.local_rank)
+        if world > 1:
+            import torch.distributed as dist_mod
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist_mod.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist_mod.init_process_group("gloo")
+            self.dist = dist_mod
+            if dist_mod.get_world_size() != world:
+                raise SystemExit(f"process group has {dist_mod.get_world_size()} ranks, expected {world}")
 
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def sync_barrier(self):
+        if self.gpu:
+            self.torch.cuda.synchronize()
+        self.barrier()
+
+    def max(self, *vals):
+        if self.dist is None:
+            return [float(v) for v in vals]
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(x) for x in t]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed_decode(rk: Ranks, sess, K: int, W: int):
+    """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides.
+    Returns (max-over-ranks wall seconds, max-over-ranks HIP-event milliseconds on the library's stream)."""
+    if W > 0:
+        sess.decode(W)
+    sess.sync()
+    rk.sync_barrier()
+    t0 = time.perf_counter()
+    ev_ms = sess.decode_timed(K)          # HIP events on the library's own stream + stream sync
+    rk.sync_barrier()
+    dt = time.perf_counter() - t0
+    return rk.max(dt, ev_ms)
+
+
+def sharded_workload(rk: Ranks, cb, model, total: int, s0: int, dtype: str, K: int, W: int, d: int):
+    """configs[3]: `total` utterances (prompt seeds 1000 + u) partitioned over the ranks by shard.local_indices; every
+    rank decodes its block as ONE batched session for W + K steps; the token vectors come back in utterance order
+    through shard.decode_sharded (the only exchange: int vectors, no activation ever crosses a GPU boundary).
+    The timed region holds the K decode steps AND the gather."""
+    from chatterbox_amd import shard
+    mine = shard.local_indices(total, rk.world, rk.rank)
+    embs = [prompt_embeds(s0, d, u) for u in mine]
+    tp0 = time.perf_counter()
+    sess, err = None, None
+    try:
+        if mine:
+            sess = cb.Session(model, embs, max_new_tokens=K + W + 8, top_p=0.0, mask_stop=True, first_utterance_id=mine[0])
+            sess.sync()
+            if W > 0:
+                sess.decode(W)
+                sess.sync()
+    except Exception as e:      # e.g. out of memory on one rank: every rank must learn of it before the first barrier
+        err = e
+    prefill_ms = (time.perf_counter() - tp0) * 1e3
+    if rk.max(1.0 if err is not None else 0.0)[0] > 0:
+        if sess is not None:
+            sess.end()
+        raise RuntimeError(f"session set-up failed on a rank: {err}")
+    ev = [0.0]
+
+    def decode(ids):
+        ev[0] = sess.decode_timed(K)
+        return [sess.tokens(i)[W:W + K] for i in range(len(ids))]
+
+    rk.sync_barrier()
+    t0 = time.perf_counter()
+    toks = shard.decode_sharded(decode, total, rk.world, rk.rank, rk.dist)
+    rk.sync_barrier()
+    dt = time.perf_counter() - t0
+    dt, ev_ms = rk.max(dt, ev[0])
+    if sess is not None:
+        sess.end()
+    assert len(toks) == total and all(len(t) == K for t in toks), "sharded decode lost tokens"
+    rows = 2 * max(len(shard.local_indices(total, rk.world, r)) for r in range(rk.world))
+    kv16 = kv_is_bf16(dtype, rows)
+    L_avg = s0 + W + (K - 1) / 2.0
+    bstep = step_bytes(model.info, rows, L_avg, 4 if dtype == "f32" else 2, 2 if kv16 else 4)   # busiest rank
+    step_us = ev_ms * 1e3 / K
+    return {"utterances": total, "ranks": rk.world, "rows_on_busiest_rank": rows, "s0": s0, "steps": K, "warmup": W,
+            "dtype": f"{dtype}-weights/{'bf16' if kv16 else 'fp32'}-kv", "scaling": "strong",
+            "tokens_per_s": round(total * K / dt, 1), "ms_per_step": round(dt * 1e3 / K, 4),
+            "hip_event_ms_per_step": round(ev_ms / K, 4), "prefill_ms": round(prefill_ms, 1),
+            "bytes_per_step_per_gpu": int(bstep), "GBps_per_gpu": round(bstep / (step_us * 1e-6) / 1e9, 1),
+            "frac": round(bstep / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "token_checksum": int(sum(int(t.sum()) for t in toks) % (1 << 31))}
+
+
+def run(args, world, rank, local_rank):
+    rk = Ranks(world, rank, local_rank, args.backend)
+    torch = rk.torch
     import chatterbox_amd as cb
     from chatterbox_amd import synth
 
     dims = synth.FULL
     if rank == 0:
-        path = synth.ensure_checkpoint(dims, 1234)
-    barrier()
+        synth.ensure_checkpoint(dims, 1234)
+    rk.barrier()
     path = synth.checkpoint_path(dims, 1234)
     if not os.path.exists(path):          # ranks on another filesystem view
         path = synth.ensure_checkpoint(dims, 1234, root=f"/tmp/t3mi_synth_r{rank}")
-    model = cb.load_t3(path, device=local_rank, dtype=args.dtype)
+    strong = args.total_utterances > 0
+    dtype = args.dtype or ("bf16" if strong else "f32")
+    s0 = args.s0 or (64 if strong else 52)
+    K, W = args.steps, args.warmup
+    model = cb.load_t3(path, device=rk.local_rank, dtype=dtype)
     info = model.info
+    d = dims.hidden_size
+    b_w = 4 if dtype == "f32" else 2
+    out = None
+
+    if strong:
+        r = sharded_workload(rk, cb, model, args.total_utterances, s0, dtype, K, W, d)
+        if rank == 0:
+            bstep, step_us = r["bytes_per_step_per_gpu"], r["hip_event_ms_per_step"] * 1e3
+            out = {
+                "metric": "T3 speech tokens/sec (whole node)", "value": r["tokens_per_s"], "unit": "tokens/s",
+                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "bf16-weights/f32-accumulate" if dtype == "bf16" else "f32",
+                "data": "synthetic",
+                "config": {"workload": f"configs[3]: {args.total_utterances} synthetic utterances x CFG pair sharded over {world} rank(s) "
+                                       f"(u -> floor(u*G/U)), greedy top_p=0, S0={s0}, {K} timed steps, Llama-520M synthetic weights, {r['dtype']}",
+                           "total_utterances": args.total_utterances, "rows_on_busiest_rank": r["rows_on_busiest_rank"], "s0": s0,
+                           "parallelism": f"utterance-sharded x{world} (no collectives; token vectors gathered by shard.decode_sharded)"},
+                "world_size_observed": world, "hip_event_ms_per_step": r["hip_event_ms_per_step"], "prefill_ms": r["prefill_ms"],
+                "token_checksum": r["token_checksum"],
+                "roofline": {"bound": "hbm", "kernel": "decode_step of the busiest rank (replayed HIP graph)", "achieved": r["GBps_per_gpu"],
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac"], "traffic": None,
+                             "bytes_per_launch": bstep, "avg_launch_us": round(step_us, 2)},
+                "cpu_baseline": None,
+            }
+        model.close()
+        return rk, out
+
+    # ---- weak scaling: every rank decodes U utterances of its own (U = 1: configs[1]) ----
     U = args.utterances
     rows = 2 * U
-    K, W = args.steps, args.warmup
-    embs = [prompt_embeds(args.s0, dims.hidden_size, rank * U + u) for u in range(U)]
+    embs = [prompt_embeds(s0, d, rank * U + u) for u in range(U)]
     torch.cuda.synchronize()
     tp0 = time.perf_counter()
-    sess = cb.Session(model, embs, max_new_tokens=K + W + 8, top_p=0.0, mask_stop=True)
+    sess = cb.Session(model, embs, max_new_tokens=K + W + 8, top_p=0.0, mask_stop=True, first_utterance_id=rank * U)
     sess.sync()
     prefill_ms = (time.perf_counter() - tp0) * 1e3   # prompt upload + cache allocation + prefill, host wall clock
-
-    if W > 0:
-        sess.decode(W)
-    sess.sync()
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    ev_ms = sess.decode_timed(K)          # HIP events on the library's own stream + stream sync
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, ev_ms = float(t[0]), float(t[1])
+    dt, ev_ms = timed_decode(rk, sess, K, W)
     ntok, _ = sess.status()
     assert int(ntok.min()) == W + K, (ntok, W, K)
 
-    b_w = 4 if args.dtype == "f32" else 2
-    L_avg = args.s0 + W + (K - 1) / 2.0          # cache length before the step, averaged over the timed steps
-    # the library keeps a bf16 KV cache when bf16 weights meet more than 4 activation rows (DESIGN.md §2)
-    kv_bf16 = args.dtype == "bf16" and rows > 4 and os.environ.get("T3MI_KV", "")[:1] != "f"
-    bstep = step_bytes(info, rows, L_avg, b_w, 2 if kv_bf16 else 4)
+    L_avg = s0 + W + (K - 1) / 2.0          # cache length before the step, averaged over the timed steps
+    kv16 = kv_is_bf16(dtype, rows)
+    bstep = step_bytes(info, rows, L_avg, b_w, 2 if kv16 else 4)
     step_us = ev_ms * 1e3 / K
     achieved = bstep / (step_us * 1e-6) / 1e9
+    n_launch = 2 + 5 * info.n_layers
     roof = {"bound": "hbm", "kernel": "decode_step (1 sampler + 30x[qkv_rope_kv, attn_decode, o_proj_resid, "
             "gate_up_swiglu, down_resid] + head; replayed HIP graph)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "bytes_per_launch": int(bstep), "avg_launch_us": round(step_us, 2)}
+    if rows <= 4:
+        # the step is a chain of n_launch DEPENDENT launches; a dependent boundary costs 1.2-1.9 us on this part
+        # (MI355X_MICROARCH.md price list, row "boundary") and a kernel needs ~2 us from wave start to its last
+        # load's return before its first byte of output, so the chain has a latency floor beside its HBM time
+        hbm_us = bstep / (HBM_PEAK_GBS * 1e3)
+        floor_us = n_launch * 3.0
+        roof["note"] = (f"{n_launch} dependent launches per step, {bstep / n_launch / 1e6:.1f} MB each on average: HBM time at peak "
+                        f"{hbm_us:.0f} us + per-launch fixed cost (~1.5 us boundary + ~1.5 us ramp/drain) {floor_us:.0f} us "
+                        f"=> floor ~{hbm_us + floor_us:.0f} us = {hbm_us / (hbm_us + floor_us):.2f} of peak; the 0.50 target of "
+                        f"north_star is not reachable with one launch per all-to-all edge at {rows} rows (DESIGN.md §4)")
     # HBM traffic per step from the committed rocprofv3 PMC passes of this same command
     # (scripts/profile_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM); bench.py cannot run
     # the profiler on itself, so the number is only attached when the workload matches.
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         wl = tj.get("workload", {})
-        if wl.get("dtype") == args.dtype and wl.get("utterances_per_gpu") == U and wl.get("s0") == args.s0:
+        if wl.get("dtype") == dtype and wl.get("utterances_per_gpu") == U and wl.get("s0") == s0:
             roof["traffic"] = int(tj["hbm_bytes_per_step"])
             roof["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " + str(wl.get("steps")) + ")"
     except Exception:
@@ -200,7 +384,7 @@ def main():
                     a["us"] += k["total_us"] / reps
             roof["per_kernel_note"] = ("eager launches bracketed by HIP events, one step at a time: each figure includes the "
                                        "launch gap, so they sum to more than avg_launch_us of the replayed graph; the "
-                                       "in-graph kernel durations are in profiles/r01_kernel_stats.csv")
+                                       "in-graph kernel durations are in profiles/r02_kernel_stats.csv")
             roof["per_kernel"] = [
                 {"name": n, "launches_per_step": a["launches"], "avg_us": round(a["us"] / max(a["launches"], 1), 2),
                  "GB/s": round(a["bytes"] / max(a["us"], 1e-9) / 1e3, 1)} for n, a in acc.items()]
@@ -214,13 +398,16 @@ def main():
         try:
             src = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
             dst = torch.empty_like(src)
+
             def timed(fn, reps=10):
-                fn(); torch.cuda.synchronize()
+                fn()
+                torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):
                     fn()
-                e1.record(); torch.cuda.synchronize()
+                e1.record()
+                torch.cuda.synchronize()
                 return e0.elapsed_time(e1) * 1e-3 / reps
             nbytes = src.numel() * 4
             roof["measured_copy_GBps"] = round(2 * nbytes / timed(lambda: dst.copy_(src)) / 1e9, 1)
@@ -229,37 +416,76 @@ def main():
         except Exception as e:
             roof["measured_copy_error"] = str(e)
 
+    # ---- attachments: the other regimes of BASELINE's metric, measured after the headline region ----
+    attach = {}
+    if not args.no_attach and U == 1 and dtype == "f32":
+        try:
+            m16 = cb.load_t3(path, device=rk.local_rank, dtype="bf16")
+            try:
+                if world == 1:
+                    # configs[2]: 64 utterances x 400 tokens batched on one GPU, bf16 weights + bf16 KV, all 400 steps timed
+                    e64 = [prompt_embeds(64, d, u) for u in range(64)]
+                    s64 = cb.Session(m16, e64, max_new_tokens=408, top_p=0.0, mask_stop=True)
+                    s64.sync()
+                    dt64, ev64 = timed_decode(rk, s64, 400, 0)
+                    s64.end()
+                    b64 = step_bytes(m16.info, 128, 64 + 399 / 2.0, 2, 2)
+                    us64 = ev64 * 1e3 / 400
+                    attach["batch64"] = {
+                        "workload": "configs[2]: 64 synthetic utterances x CFG pair (128 rows) x 400 speech tokens on one MI355X, greedy, "
+                                    "S0=64 (L 64 -> 464), bf16 weights + bf16 KV cache, fp32 accumulate",
+                        "tokens_per_s": round(64 * 400 / dt64, 1), "ms_per_step": round(dt64 * 1e3 / 400, 4),
+                        "hip_event_ms_per_step": round(ev64 / 400, 4), "steps": 400, "bytes_per_step": int(b64),
+                        "GBps": round(b64 / (us64 * 1e-6) / 1e9, 1), "frac": round(b64 / (us64 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                # configs[3]: 512 utterances sharded over the ranks of this run
+                attach["cfg4_512utt"] = sharded_workload(rk, cb, m16, 512, 64, "bf16", 400, 0, d)
+            finally:
+                m16.close()
+        except Exception as e:   # an attachment must never cost the headline line
+            attach["attach_error"] = f"{type(e).__name__}: {e}"
+
     if rank == 0:
         cpu = None
         if world == 1 and args.cpu_steps > 0:
-            cpu = cpu_baseline(args.cpu_steps, args.s0, embs[0])
-        total_tokens = n_gpus * U * K
+            cpu = cpu_baseline(args.cpu_steps, s0, embs[0])
+        total_tokens = world * U * K
         out = {
             "metric": "T3 speech tokens/sec (whole node)",
             "value": round(total_tokens / dt, 2),
             "unit": "tokens/s",
-            "n_gpus": n_gpus, "steps": K, "warmup": W,
+            "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt * 1e3 / K, 5),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "f32" else "bf16-weights/f32-accumulate",
+            "dtype": "f32" if dtype == "f32" else "bf16-weights/f32-accumulate",
             "data": "synthetic",
             "config": {"workload": f"{'configs[1]' if U == 1 else 'configs[2]-shaped'}: {U} utterance(s)/GPU x CFG cond/uncond pair "
-                                   f"({rows} rows), greedy top_p=0, S0={args.s0}, Llama-520M (30x d1024/F4096, V8194) synthetic "
-                                   f"weights in the reference safetensors layout, {args.dtype} weights, "
-                                   f"{'bf16' if kv_bf16 else 'fp32'} KV cache",
-                       "utterances_per_gpu": U, "rows_per_gpu": rows, "s0": args.s0,
-                       "parallelism": f"utterance-sharded x{n_gpus} (no collectives)"},
+                                   f"({rows} rows), greedy top_p=0, S0={s0}, Llama-520M (30x d1024/F4096, V8194) synthetic "
+                                   f"weights in the reference safetensors layout, {dtype} weights, "
+                                   f"{'bf16' if kv16 else 'fp32'} KV cache",
+                       "utterances_per_gpu": U, "rows_per_gpu": rows, "s0": s0,
+                       "parallelism": f"utterance-sharded x{world} (no collectives)"},
+            "world_size_observed": world,
             "hip_event_ms_per_step": round(ev_ms / K, 5),
             "prefill_ms": round(prefill_ms, 3),   # rank 0: session set-up + prefill of its utterances (not in `value`)
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        out.update(attach)
+    return rk, out
+
+
+def main():
+    args = parse()
+    world, rank, local_rank, spawn = resolve_world(args.gpus)
+    if spawn:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    rk, out = run(args, world, rank, local_rank)
+    if rank == 0 and out is not None:
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    rk.close()
 
 
 if __name__ == "__main__":

@@ -32,6 +32,7 @@ class Params(C.Structure):
         ("max_cache_len", C.c_int32),
         ("mask_stop", C.c_int32),
         ("seed", C.c_uint64),
+        ("first_utterance_id", C.c_int64),
     ]
 
 
@@ -69,6 +70,7 @@ SYMBOLS = {
                                       _IP, C.c_int32, _IP]),
     "t3mi_prompt_shape": (C.c_int, [_H, C.POINTER(Cond), C.c_int, C.c_float, _IP, _IP, _IP]),
     "t3mi_prepare_input_embeds": (C.c_int, [_H, C.POINTER(Cond), _IP, C.c_int, C.c_float, C.c_int32, _FP, C.c_size_t]),
+    "t3mi_prepare_input_embeds_static": (C.c_int, [_H, C.POINTER(Cond), _IP, C.c_int, C.c_float, C.c_int32, C.c_void_p, C.c_size_t]),
     "t3mi_generate_tokens": (C.c_int, [_H, C.POINTER(Cond), _IP, C.c_int, C.POINTER(Params), _IP, C.c_int32, _IP]),
     "t3mi_generate_batch_tokens": (C.c_int, [_H, C.c_int, C.POINTER(Cond), C.POINTER(_IP), _IP, C.POINTER(Params),
                                              _IP, C.c_int32, _IP]),

@@ -438,7 +438,9 @@ __global__ __launch_bounds__(256, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kerne
 
     __shared__ float sm_m[32], sm_l[32];
     __shared__ __attribute__((aligned(16))) float sm_acc[32][kHeadDim + 4];
-    const int h = blockIdx.x, qi = blockIdx.y;
+    // flat grid: block = qi * H + h (the heads of an item are adjacent, as they are in the cache); a 2-D grid with the
+    // items in y is capped at 65535 items, which a prefill of a few hundred prompts exceeds
+    const int h = (int)(blockIdx.x % (unsigned)a.n_heads), qi = (int)(blockIdx.x / (unsigned)a.n_heads);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kg = lane >> 3, dc = lane & 7;
     const int pos = a.posmap[qi];
@@ -1298,7 +1300,8 @@ hipError_t launch_fold_partials(float* x, const float* part, int ks, const float
 hipError_t launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
     if (!a.q || !a.kcache || !a.vcache || !a.posmap || !a.out || a.M <= 0 || a.n_heads <= 0 || a.max_len <= 0)
         return hipErrorInvalidValue;
-    const dim3 grid(a.n_heads, a.M), block(256);
+    if ((long long)a.M * a.n_heads > 0x7FFFFFFFLL) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)a.M * (unsigned)a.n_heads), block(256);
     if (a.kv_bf16 && a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, uint16_t>), grid, block, 0, s, a);
     else if (a.kv_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, float>), grid, block, 0, s, a);
     else if (a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<float, uint16_t>), grid, block, 0, s, a);

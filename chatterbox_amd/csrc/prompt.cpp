@@ -201,6 +201,16 @@ int prompt_shape(const PromptModel* pm, const PromptEnv& env, const PromptCond& 
     return T3MI_OK;
 }
 
+void prompt_scratch_need(const PromptModel* pm, const PromptEnv& env, const PromptCond& c, int n_text, size_t* rows_floats,
+                         size_t* n_ids) {
+    const bool llama = env.variant == T3MI_VARIANT_LLAMA;
+    const int nq = (pm && pm->perceiver) ? pm->n_query : 0;
+    const int mk = std::max(std::max(c.n_cond, 0), nq);
+    // scratch rows: E, N2, K, V [mk] | N1, Q, A, P [nq]
+    *rows_floats = (size_t)(4 * mk + 4 * nq) * (size_t)(pm ? pm->d : 0);
+    *n_ids = (size_t)std::max(c.n_cond, 0) + (size_t)std::max(n_text, 0) + (llama ? 2 : 0) + 1;
+}
+
 namespace {
 
 // y[M, d] = A[M, K] W[d, K]^T + b (+ resid)
@@ -222,7 +232,7 @@ hipError_t linear(const float* A, const float* W, const float* b, const float* r
 }  // namespace
 
 int prompt_build(PromptModel* pm, const PromptEnv& env, const PromptCond& c, const int32_t* text_tokens, int n_text,
-                 float cfg_weight, float* out_dev, std::string& err) {
+                 float cfg_weight, float* out_dev, std::string& err, const PromptScratch* ext) {
     int rows = 0, s0 = 0, lc = 0;
     int rc = prompt_shape(pm, env, c, n_text, cfg_weight, &rows, &s0, &lc, err);
     if (rc) return rc;
@@ -254,31 +264,63 @@ int prompt_build(PromptModel* pm, const PromptEnv& env, const PromptCond& c, con
         return T3MI_ERR_ARG;
     }
     // ids on device: [cond tokens | text tokens (with start / stop) | start speech token]
-    pm->hold_ids.emplace_back();
-    std::vector<int32_t>& ids = pm->hold_ids.back();
-    ids.insert(ids.end(), c.cond_tokens, c.cond_tokens + n_cond);
-    if (llama) ids.push_back(kStartText);
-    ids.insert(ids.end(), text_tokens, text_tokens + n_text);
-    if (llama) ids.push_back(kStopText);
-    ids.push_back(env.start_token);
-    if ((pm->ids_off + ids.size()) * 4 > pm->ids_arena.bytes || (pm->spk_off + pm->spk_dim) * 4 > pm->spk_arena.bytes) {
-        err = "prompt: staging arenas too small (prompt_batch_begin not called for this batch)";
-        return T3MI_ERR_STATE;
+    const int nq = pm->perceiver ? pm->n_query : 0;
+    const int mk = std::max(n_cond, nq);
+    const size_t n_ids = (size_t)n_cond + (size_t)n_tt + 1;
+    const size_t rows_floats = (size_t)(4 * mk + 4 * nq) * d;
+    int* ids_dev = nullptr;
+    float* spk = nullptr;
+    float* E = nullptr;
+    if (ext != nullptr) {
+        // caller-owned working memory: nothing is allocated; the three small host -> device copies below read the
+        // caller's arrays directly, which stay valid until the caller has synchronised the stream
+        if (!ext->rows || !ext->ids || !ext->spk || n_ids > ext->ids_cap || (size_t)pm->spk_dim > ext->spk_cap ||
+            rows_floats > ext->rows_floats) {
+            err = "prompt: inputs exceed the fixed working memory (" + std::to_string(n_ids) + " ids of " +
+                  std::to_string(ext->ids_cap) + ", " + std::to_string(rows_floats) + " scratch floats of " +
+                  std::to_string(ext->rows_floats) + ")";
+            return T3MI_ERR_ARG;
+        }
+        ids_dev = ext->ids;
+        spk = ext->spk;
+        E = ext->rows;
+        int* q = ids_dev;
+        if (n_cond > 0) PHIP(hipMemcpyAsync(q, c.cond_tokens, (size_t)n_cond * 4, hipMemcpyHostToDevice, st));
+        q += n_cond;
+        // start / stop text tokens and the start speech token are constants: written by 4-byte fills, no host buffer
+        if (llama) PHIP(hipMemsetD32Async((hipDeviceptr_t)(q++), kStartText, 1, st));
+        if (n_text > 0) PHIP(hipMemcpyAsync(q, text_tokens, (size_t)n_text * 4, hipMemcpyHostToDevice, st));
+        q += n_text;
+        if (llama) PHIP(hipMemsetD32Async((hipDeviceptr_t)(q++), kStopText, 1, st));
+        PHIP(hipMemsetD32Async((hipDeviceptr_t)q, env.start_token, 1, st));
+        PHIP(hipMemcpyAsync(spk, c.speaker_emb, (size_t)pm->spk_dim * 4, hipMemcpyHostToDevice, st));
+    } else {
+        pm->hold_ids.emplace_back();
+        std::vector<int32_t>& ids = pm->hold_ids.back();
+        ids.insert(ids.end(), c.cond_tokens, c.cond_tokens + n_cond);
+        if (llama) ids.push_back(kStartText);
+        ids.insert(ids.end(), text_tokens, text_tokens + n_text);
+        if (llama) ids.push_back(kStopText);
+        ids.push_back(env.start_token);
+        if ((pm->ids_off + ids.size()) * 4 > pm->ids_arena.bytes || (pm->spk_off + pm->spk_dim) * 4 > pm->spk_arena.bytes) {
+            err = "prompt: staging arenas too small (prompt_batch_begin not called for this batch)";
+            return T3MI_ERR_STATE;
+        }
+        ids_dev = pm->ids_arena.as<int>() + pm->ids_off;
+        pm->ids_off += ids.size();
+        PHIP(hipMemcpyAsync(ids_dev, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
+        // scratch rows (reused by every utterance, in stream order): E, N2, K, V [mk] | N1, Q, A, P [nq]
+        PHIP(pm->scratch.reserve((rows_floats + 16) * 4));
+        spk = pm->spk_arena.as<float>() + pm->spk_off;
+        pm->spk_off += pm->spk_dim;
+        E = pm->scratch.as<float>();
+        pm->hold_spk.emplace_back(c.speaker_emb, c.speaker_emb + pm->spk_dim);
+        PHIP(hipMemcpyAsync(spk, pm->hold_spk.back().data(), (size_t)pm->spk_dim * 4, hipMemcpyHostToDevice, st));
     }
-    int* ids_dev = pm->ids_arena.as<int>() + pm->ids_off;
-    pm->ids_off += ids.size();
-    PHIP(hipMemcpyAsync(ids_dev, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
     const int* id_cond = ids_dev;
     const int* id_text = id_cond + n_cond;
     const int* id_bos = id_text + n_tt;
 
-    // scratch rows (reused by every utterance, in stream order): E, N2, K, V [mk] | N1, Q, A, P [nq]
-    const int nq = pm->perceiver ? pm->n_query : 0;
-    const int mk = std::max(n_cond, nq);
-    PHIP(pm->scratch.reserve(((size_t)(4 * mk + 4 * nq) * d + 16) * 4));
-    float* spk = pm->spk_arena.as<float>() + pm->spk_off;
-    pm->spk_off += pm->spk_dim;
-    float* E = pm->scratch.as<float>();
     float* N2 = E + (size_t)mk * d;
     float* K = N2 + (size_t)mk * d;
     float* V = K + (size_t)mk * d;
@@ -286,8 +328,6 @@ int prompt_build(PromptModel* pm, const PromptEnv& env, const PromptCond& c, con
     float* Q = N1 + (size_t)nq * d;
     float* A = Q + (size_t)nq * d;
     float* P = A + (size_t)nq * d;
-    pm->hold_spk.emplace_back(c.speaker_emb, c.speaker_emb + pm->spk_dim);
-    PHIP(hipMemcpyAsync(spk, pm->hold_spk.back().data(), (size_t)pm->spk_dim * 4, hipMemcpyHostToDevice, st));
 
     float* row0 = out_dev;
     // speaker projection (R/t3.R:285-286)

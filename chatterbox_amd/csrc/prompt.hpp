@@ -42,8 +42,24 @@ int prompt_batch_begin(PromptModel* pm, size_t total_ids, int n_utt, std::string
 // shape of the prompt these inputs give: rows (2 with CFG on the Llama variant), S0, conditioning length
 int prompt_shape(const PromptModel* pm, const PromptEnv& env, const PromptCond& c, int n_text, float cfg_weight, int* rows,
                  int* s0, int* len_cond, std::string& err);
-// writes [rows, s0, d] fp32 at out_dev (asynchronous on env.stream; host inputs are copied before returning)
+// Caller-owned working memory for one prompt_build call (the entry point that allocates nothing): `rows` holds the
+// perceiver's intermediate rows, `ids` the uploaded token ids, `spk` the uploaded speaker vector.  Capacities in elements.
+struct PromptScratch {
+    float* rows = nullptr;
+    size_t rows_floats = 0;
+    int* ids = nullptr;
+    size_t ids_cap = 0;
+    float* spk = nullptr;
+    size_t spk_cap = 0;
+};
+// scratch floats / ids prompt_build needs for these inputs (what a PromptScratch must hold)
+void prompt_scratch_need(const PromptModel* pm, const PromptEnv& env, const PromptCond& c, int n_text, size_t* rows_floats,
+                         size_t* n_ids);
+// writes [rows, s0, d] fp32 at out_dev (asynchronous on env.stream; host inputs are copied before returning).
+// ext == nullptr: working memory comes from the model's own (growing, hipMalloc'ed) buffers, sized by prompt_batch_begin.
+// ext != nullptr: working memory is *ext, nothing is allocated or kept; the call returns T3MI_ERR_ARG if *ext is too
+// small, and the host inputs must stay valid until the stream has drained (the caller synchronises).
 int prompt_build(PromptModel* pm, const PromptEnv& env, const PromptCond& c, const int32_t* text_tokens, int n_text,
-                 float cfg_weight, float* out_dev, std::string& err);
+                 float cfg_weight, float* out_dev, std::string& err, const PromptScratch* ext = nullptr);
 
 }  // namespace t3mi

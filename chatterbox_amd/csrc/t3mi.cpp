@@ -6,6 +6,7 @@
 // R/t3.R:530,574 ; src/t3_decode.cpp:339,361-362).
 #include "t3mi.h"
 
+#include <hip/hip_runtime.h>
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -21,9 +22,36 @@
 #include "prompt.hpp"
 #include "safetensors.hpp"
 
+// ---- fixed working memory of t3mi_prepare_input_embeds_static (the entry point that allocates nothing) -------------
+// One array per GPU, part of the code object: every GPU the library runs on holds it until the process ends.
+// Layout: [0, kStaticRowsFloats * 4) perceiver rows | ids | speaker vector.  In host code the NAME `scratch` is only a
+// handle for hipGetSymbolAddress: kernels and copies take the per-device address that call returns (static_scratch()).
+constexpr size_t kStaticRowsFloats = 2u << 20;   // (4 * max(n_cond, n_query) + 4 * n_query) * d floats: 8 MiB
+constexpr size_t kStaticIds = 4096;              // conditioning + text ids (+ start / stop / BOS)
+constexpr size_t kStaticSpk = 1024;              // speaker-embedding floats
+constexpr size_t kStaticScratchBytes = kStaticRowsFloats * 4 + kStaticIds * 4 + kStaticSpk * 4;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 namespace {
 
 thread_local std::string g_err = "";
+
+constexpr int kMaxDevices = 64;
+void* g_static_scratch[kMaxDevices] = {};   // device address of `scratch` on each GPU, filled by t3mi_open
+
+// with `device` current: the address of this GPU's copy of `scratch` (looked up once per device)
+hipError_t static_scratch(int device, void** out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (g_static_scratch[device] == nullptr) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_static_scratch[device] = p;
+    }
+    *out = g_static_scratch[device];
+    return hipSuccess;
+}
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -116,6 +144,7 @@ struct t3mi_model {
     const float* head_b_f = nullptr;
     int64_t weight_bytes = 0;
     std::unique_ptr<Session> sess;
+    void* static_scratch = nullptr;        // this GPU's copy of the file-scope `scratch` array (hipGetSymbolAddress at open)
     t3mi::PromptModel* prompt = nullptr;   // text_emb / cond_enc.* tensors (nullptr: decode-only checkpoint)
     DevBuf prompt_buf;                     // prompts built on device, alive until the next build
     bool use_graph = true;
@@ -692,6 +721,9 @@ int run_sampler(t3mi_model* m, Session* s, StepTimer* tm) {
     a.cfg_w = p.cfg_weight; a.temperature = p.temperature; a.top_p = p.top_p; a.min_p = p.min_p;
     a.penalty = p.repetition_penalty; a.variant = p.sampler; a.top_k = p.top_k; a.stop_token = p.stop_token;
     a.mask_stop = p.mask_stop; a.max_new_tokens = p.max_new_tokens; a.seed = p.seed;
+    a.utt_base = (unsigned long long)p.first_utterance_id;
+    a.cache_cap = p.max_cache_len > 0 ? p.max_cache_len : 0;
+    a.cap_extra = m->variant == T3MI_VARIANT_TURBO ? 1 : 0;
     a.start_token = p.start_token;
     a.seen = s->seen.as<uint8_t>(); a.tokens = s->tokens.as<int>(); a.cap = s->cap;
     a.n_tokens = s->n_tokens.as<int>(); a.done = s->done.as<int>(); a.rowpos = s->rowpos.as<int>();
@@ -805,6 +837,7 @@ int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model*
                 if (v[i] == 1 || v[i] == 2 || v[i] == 4) m->tune_rows[i] = v[i];
     }
     HIPCHK(t3k::init_device());
+    HIPCHK(static_scratch(device, &m->static_scratch));   // once per device, with that device current
     HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     int rc = variant == T3MI_VARIANT_TURBO ? load_turbo(m.get(), st) : load_llama(m.get(), st);
     if (rc) {
@@ -906,10 +939,10 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     s->max_s0 = max_s0;
     int max_new = p->max_new_tokens;
     if (p->max_cache_len > 0) {
-        // t3_inference_cpp: max_gen_tokens = min(max_new_tokens, max_cache_len - cond_len - 1)  (R/t3.R:996)
-        const int room = p->max_cache_len - max_s0 - 1;
-        if (room <= 0) return fail(T3MI_ERR_ARG, "prompt does not fit max_cache_len (R/llama_traced.R:343-345)");
-        max_new = std::min(max_new, room);
+        // t3_inference_cpp: max_gen_tokens = min(max_new_tokens, max_cache_len - cond_len - 1)  (R/t3.R:996), per
+        // utterance: the sampler applies each utterance's own clamp, the host sizes the token buffers for the largest
+        if (p->max_cache_len - max_s0 - 1 <= 0) return fail(T3MI_ERR_ARG, "prompt does not fit max_cache_len (R/llama_traced.R:343-345)");
+        max_new = std::min(max_new, p->max_cache_len - min_s0 - 1);
     }
     if (max_new + 1 > m->max_pos) max_new = m->max_pos - 1;  // learned speech pos-emb rows (R/t3.R:349)
     // Turbo samples one token from the prefill logits and then up to max_new_tokens more (R/t3.R:1614-1658)
@@ -1033,47 +1066,61 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     if (pfenv && std::strcmp(pfenv, "gemm") == 0) gemm_prefill = true;
     if (s->kv_bf16) gemm_prefill = true;   // the one-position decode kernels write fp32 cache slots
     if (gemm_prefill) {
-        size_t items = 0;
-        for (int u = 0; u < n_utt; ++u) items += (size_t)rpu * s0[u];
-        std::vector<const float*> isrc(items);
-        std::vector<int32_t> ipos(items), irow(items);
-        std::vector<const float*> last(rows);
-        size_t it = 0;
+        // Rows are prefilled in groups of at most kPrefillItems (row, position) items (a row only attends to its own
+        // cache row, so groups are independent): the scratch stays bounded however many prompts a batch holds.
+        constexpr size_t kPrefillItems = 32768;
+        std::vector<std::pair<int, int>> groups;   // [row begin, row end)
+        size_t max_items = 0;
+        for (int r0 = 0; r0 < (int)rows;) {
+            size_t n = 0;
+            int r1 = r0;
+            while (r1 < (int)rows && (r1 == r0 || n + (size_t)s0[r1 / rpu] <= kPrefillItems)) n += (size_t)s0[r1++ / rpu];
+            groups.emplace_back(r0, r1);
+            max_items = std::max(max_items, n);
+            r0 = r1;
+        }
         DevBuf xpf, qpf, xnpf, aopf, hpf, dsrc, dpos, drow, dlast;
         const size_t as = (m->wdtype == T3MI_W_BF16 && !pf_act_f32) ? 2 : 4;
-        HIPCHK(xpf.alloc(items * d * 4));
-        for (int r = 0; r < (int)rows; ++r) {
-            const int u = r / rpu;
-            for (int t = 0; t < s0[u]; ++t, ++it) {
-                isrc[it] = row_ptr[r] + (size_t)t * d;
-                ipos[it] = t;
-                irow[it] = r;
-            }
-            last[r] = xpf.as<float>() + (it - 1) * d;
-        }
-        HIPCHK(qpf.alloc(items * d * 4));
-        HIPCHK(xnpf.alloc(items * d * as));
-        HIPCHK(aopf.alloc(items * d * as));
-        HIPCHK(hpf.alloc(items * F * as));
-        HIPCHK(dsrc.alloc(items * sizeof(void*)));
-        HIPCHK(dpos.alloc(items * 4));
-        HIPCHK(drow.alloc(items * 4));
+        HIPCHK(xpf.alloc(max_items * d * 4));
+        HIPCHK(qpf.alloc(max_items * d * 4));
+        HIPCHK(xnpf.alloc(max_items * d * as));
+        HIPCHK(aopf.alloc(max_items * d * as));
+        HIPCHK(hpf.alloc(max_items * F * as));
+        HIPCHK(dsrc.alloc(max_items * sizeof(void*)));
+        HIPCHK(dpos.alloc(max_items * 4));
+        HIPCHK(drow.alloc(max_items * 4));
         HIPCHK(dlast.alloc(rows * sizeof(void*)));
-        HIPCHK(hipMemcpyAsync(dsrc.p, isrc.data(), items * sizeof(void*), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(dpos.p, ipos.data(), items * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(drow.p, irow.data(), items * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(dlast.p, last.data(), rows * sizeof(void*), hipMemcpyHostToDevice, st));
-        HIPCHK(t3k::launch_gather_rows(dsrc.as<const float*>(), xpf.as<float>(), (int)items, m->d, st));
-        GemmCtx c;
-        c.M = (int)items; c.x = xpf.as<float>(); c.q = qpf.as<float>();
-        c.xn = xnpf.p; c.attn_out = aopf.p; c.hact = hpf.p;
-        c.posmap = dpos.as<int>(); c.rowmap = drow.as<int>();
-        c.act_f32 = pf_act_f32;
-        if ((rc = run_layers_gemm(m, s.get(), c, nullptr))) return rc;
-        if ((rc = fold_pending(m, s.get(), c))) return rc;
-        // the last prompt position of every row feeds the first speech-head evaluation
-        HIPCHK(t3k::launch_gather_rows(dlast.as<const float*>(), s->x.as<float>(), (int)rows, m->d, st));
-        HIPCHK(hipStreamSynchronize(st));  // host vectors and the prefill scratch die here
+        std::vector<const float*> isrc, last;
+        std::vector<int32_t> ipos, irow;
+        for (const auto& grp : groups) {
+            isrc.clear(); ipos.clear(); irow.clear(); last.clear();
+            for (int r = grp.first; r < grp.second; ++r) {
+                const int u = r / rpu;
+                for (int t = 0; t < s0[u]; ++t) {
+                    isrc.push_back(row_ptr[r] + (size_t)t * d);
+                    ipos.push_back(t);
+                    irow.push_back(r);
+                }
+                last.push_back(xpf.as<float>() + (isrc.size() - 1) * d);
+            }
+            const size_t items = isrc.size();
+            const int grows = grp.second - grp.first;
+            HIPCHK(hipMemcpyAsync(dsrc.p, isrc.data(), items * sizeof(void*), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dpos.p, ipos.data(), items * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(drow.p, irow.data(), items * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(dlast.p, last.data(), (size_t)grows * sizeof(void*), hipMemcpyHostToDevice, st));
+            HIPCHK(t3k::launch_gather_rows(dsrc.as<const float*>(), xpf.as<float>(), (int)items, m->d, st));
+            GemmCtx c;
+            c.M = (int)items; c.x = xpf.as<float>(); c.q = qpf.as<float>();
+            c.xn = xnpf.p; c.attn_out = aopf.p; c.hact = hpf.p;
+            c.posmap = dpos.as<int>(); c.rowmap = drow.as<int>();
+            c.act_f32 = pf_act_f32;
+            if ((rc = run_layers_gemm(m, s.get(), c, nullptr))) return rc;
+            if ((rc = fold_pending(m, s.get(), c))) return rc;
+            // the last prompt position of every row feeds the first speech-head evaluation
+            HIPCHK(t3k::launch_gather_rows(dlast.as<const float*>(), s->x.as<float>() + (size_t)grp.first * d, grows, m->d, st));
+            HIPCHK(hipStreamSynchronize(st));  // the host vectors are refilled by the next group; the scratch dies after the last
+        }
     } else {
         for (int t = 0; t < max_s0; ++t) {
             t3k::EmbedArgs e;
@@ -1243,7 +1290,7 @@ int t3mi_session_profile_step(t3mi_model* m, t3mi_kstat* stats, int cap, int* n_
         const double d = m->d, F = m->F, V = m->V;
         double kvb = 0;
         for (int u = 0; u < s->n_utt; ++u)
-            if (!done[u]) kvb += (double)s->rpu * 2.0 * d * (s->s0[u] + ntok[u] + 1) * 4.0;
+            if (!done[u]) kvb += (double)s->rpu * 2.0 * d * (s->s0[u] + ntok[u] + 1) * (s->kv_bf16 ? 2.0 : 4.0);
         for (int k = 0; k < K_COUNT; ++k) {
             std::memset(&stats[k], 0, sizeof(t3mi_kstat));
             std::snprintf(stats[k].name, sizeof(stats[k].name), "%s", kKindName[k]);
@@ -1428,6 +1475,43 @@ int t3mi_prepare_input_embeds(t3mi_model* m, const t3mi_cond* cond, const int32_
     if (cap_floats < n) return fail(T3MI_ERR_ARG, "t3mi_prepare_input_embeds: output buffer too small");
     HIPCHK(hipStreamSynchronize(m->stream));
     HIPCHK(hipMemcpy(out, ptrs[0], n * 4, hipMemcpyDeviceToHost));
+    return T3MI_OK;
+}
+
+int t3mi_prepare_input_embeds_static(t3mi_model* m, const t3mi_cond* cond, const int32_t* text_tokens, int n_text,
+                                     float cfg_weight, int32_t start_token, float* out_device, size_t cap_floats) {
+    if (!m || !cond || !out_device) return fail(T3MI_ERR_ARG, "t3mi_prepare_input_embeds_static: null argument");
+    HIPCHK(hipSetDevice(m->device));
+    if (!m->static_scratch) return fail(T3MI_ERR_STATE, "t3mi_prepare_input_embeds_static: no working memory on this device");
+    const t3mi::PromptEnv env = prompt_env(m, start_token);
+    const t3mi::PromptCond pc = prompt_cond(cond);
+    std::string err;
+    int rows = 0, s0 = 0, lc = 0;
+    int rc = t3mi::prompt_shape(m->prompt, env, pc, n_text, cfg_weight, &rows, &s0, &lc, err);
+    if (rc) return fail(rc, err);
+    if (cap_floats < (size_t)rows * s0 * m->d) return fail(T3MI_ERR_ARG, "t3mi_prepare_input_embeds_static: output buffer too small");
+    size_t need_rows = 0, need_ids = 0;
+    t3mi::prompt_scratch_need(m->prompt, env, pc, n_text, &need_rows, &need_ids);
+    if (need_rows > kStaticRowsFloats || need_ids > kStaticIds || (size_t)pc.n_speaker > kStaticSpk)
+        return fail(T3MI_ERR_ARG, "t3mi_prepare_input_embeds_static: inputs exceed the fixed working memory (" +
+                                      std::to_string(need_ids) + " ids, limit " + std::to_string(kStaticIds) + "; " +
+                                      std::to_string(need_rows) + " scratch floats, limit " + std::to_string(kStaticRowsFloats) +
+                                      "; " + std::to_string(pc.n_speaker) + " speaker floats, limit " + std::to_string(kStaticSpk) +
+                                      "): use t3mi_prepare_input_embeds");
+    // m->static_scratch is the DEVICE address of this GPU's `scratch`; the array's name is never used below
+    unsigned char* base = static_cast<unsigned char*>(m->static_scratch);
+    t3mi::PromptScratch ws;
+    ws.rows = reinterpret_cast<float*>(base);
+    ws.rows_floats = kStaticRowsFloats;
+    ws.ids = reinterpret_cast<int*>(base + kStaticRowsFloats * 4);
+    ws.ids_cap = kStaticIds;
+    ws.spk = reinterpret_cast<float*>(base + kStaticRowsFloats * 4 + kStaticIds * 4);
+    ws.spk_cap = kStaticSpk;
+    rc = t3mi::prompt_build(m->prompt, env, pc, text_tokens, n_text, cfg_weight, out_device, err, &ws);
+    // the copies above read the caller's host arrays and the next call reuses the same working memory: drain the stream
+    hipError_t e = hipStreamSynchronize(m->stream);
+    if (rc) return fail(rc, err);
+    if (e != hipSuccess) return fail(T3MI_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     return T3MI_OK;
 }
 

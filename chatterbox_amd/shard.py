@@ -47,3 +47,22 @@ def decode_sharded(decode_fn: Callable[[Sequence[int]], List[np.ndarray]], n_utt
     if seen != n_utt:
         raise RuntimeError(f"gathered {seen} utterances, expected {n_utt}")
     return result
+
+
+def t3_inference_sharded(model, prompts: Sequence, text_tokens_list=None, dist=None, world: int = 1, rank: int = 0,
+                         turbo: bool = False, **kw) -> List[np.ndarray]:
+    """t3_inference_batch (or t3_inference_turbo_batch) over the ranks of one node: every rank passes the FULL
+    list of prompts (embedding arrays, or T3Cond objects with `text_tokens_list`), decodes its own contiguous
+    block on its own GPU through `model` (a T3Model on this rank's device) and receives all utterances' tokens
+    in utterance order.  Each utterance keeps the RNG stream of its global index (first_utterance_id = first
+    index of the block), so sampled output does not depend on the number of ranks."""
+    from . import t3
+
+    n_utt = len(prompts)
+    fn = t3.t3_inference_turbo_batch if turbo else t3.t3_inference_batch
+
+    def decode(mine):
+        tt = None if text_tokens_list is None else [text_tokens_list[u] for u in mine]
+        return fn(model, [prompts[u] for u in mine], tt, first_utterance_id=mine[0], **kw)
+
+    return decode_sharded(decode, n_utt, world, rank, dist)

@@ -24,8 +24,9 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["T3Model", "load_t3", "load_t3_turbo", "t3_inference", "t3_inference_cpp", "t3_inference_batch",
-           "t3_inference_turbo", "t3_inference_turbo_batch", "Session", "T3Cond", "t3_cond", "prepare_input_embeds"]
+__all__ = ["T3Model", "load_t3", "load_t3_turbo", "t3_inference", "t3_inference_cpp", "t3_inference_traced",
+           "t3_inference_batch", "t3_inference_turbo", "t3_inference_turbo_batch", "Session", "T3Cond", "t3_cond",
+           "prepare_input_embeds", "split_sentences", "drop_invalid_tokens", "tts_chunked", "SPEECH_VOCAB_SIZE"]
 
 _DT = {"f32": _lib.W_F32, "fp32": _lib.W_F32, "float32": _lib.W_F32, "bf16": _lib.W_BF16,
        "bfloat16": _lib.W_BF16}
@@ -77,7 +78,7 @@ def load_t3_turbo(path: str, device: int = 0, dtype: str = "f32", **kw) -> T3Mod
 
 
 def _params(model: T3Model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
-            sampler, max_cache_len=0, seed=0, mask_stop=False, top_k=0) -> _lib.Params:
+            sampler, max_cache_len=0, seed=0, mask_stop=False, top_k=0, first_utterance_id=0) -> _lib.Params:
     p = _lib.Params()
     model._lib.t3mi_default_params(C.byref(p))
     p.max_new_tokens = int(max_new_tokens)
@@ -93,6 +94,7 @@ def _params(model: T3Model, max_new_tokens, temperature, cfg_weight, top_p, min_
     p.max_cache_len = int(max_cache_len)
     p.mask_stop = 1 if mask_stop else 0
     p.seed = int(seed)
+    p.first_utterance_id = int(first_utterance_id)
     return p
 
 
@@ -258,11 +260,13 @@ def t3_inference_batch(model: T3Model, embeds_list: Sequence, text_tokens_list: 
                        max_new_tokens: int = 1000,
                        temperature: float = 0.8, cfg_weight: float = 0.5, top_p: float = 0.95,
                        min_p: float = 0.05, repetition_penalty: float = 1.2, seed: int = 0,
-                       mask_stop: bool = False) -> List[np.ndarray]:
+                       mask_stop: bool = False, first_utterance_id: int = 0) -> List[np.ndarray]:
     """Independent utterances decoded together (the batch axis tts_chunked leaves serial,
-    R/tts.R:462-474).  Same per-utterance semantics as t3_inference."""
+    R/tts.R:462-474).  Same per-utterance semantics as t3_inference.  Utterance u of the call draws from the
+    RNG stream (seed, first_utterance_id + u): a batch cut into several calls (or sharded over GPUs,
+    chatterbox_amd.shard) samples the same tokens as the one-call batch."""
     p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
-                _lib.SAMPLER_R, 0, seed, mask_stop)
+                _lib.SAMPLER_R, 0, seed, mask_stop, first_utterance_id=first_utterance_id)
     if text_tokens_list is not None:        # embeds_list holds T3Cond objects, one per utterance
         return _generate_tokens(model, list(embeds_list), list(text_tokens_list), p, int(max_new_tokens))
     es = [_as_embeds(model, e, cfg_weight) for e in embeds_list]
@@ -282,12 +286,12 @@ def t3_inference_turbo_batch(model: T3Model, embeds_list: Sequence, text_tokens_
                              max_new_tokens: int = 1000,
                              temperature: float = 0.8, top_k: int = 1000, top_p: float = 0.95,
                              repetition_penalty: float = 1.2, seed: int = 0, mask_stop: bool = False,
-                             keep_stop: bool = False) -> List[np.ndarray]:
+                             keep_stop: bool = False, first_utterance_id: int = 0) -> List[np.ndarray]:
     """Independent Turbo utterances decoded together; per-utterance semantics of t3_inference_turbo."""
     if model.variant != _lib.VARIANT_TURBO:
         raise ValueError("t3_inference_turbo needs a model opened with load_t3_turbo")
     p = _params(model, max_new_tokens, temperature, 0.0, top_p, 0.0, repetition_penalty,
-                _lib.SAMPLER_TURBO, 0, seed, mask_stop, top_k)
+                _lib.SAMPLER_TURBO, 0, seed, mask_stop, top_k, first_utterance_id=first_utterance_id)
     cap = int(max_new_tokens) + 1            # first token from the prefill + max_new_tokens more (R/t3.R:1614-1658)
     if text_tokens_list is not None:         # embeds_list holds T3Cond objects
         toks = _generate_tokens(model, list(embeds_list), list(text_tokens_list), p, cap)
@@ -324,6 +328,55 @@ def t3_inference_turbo(model: T3Model, cond, text_tokens=None, max_new_tokens: i
                                     repetition_penalty, seed)[0]
 
 
+SPEECH_VOCAB_SIZE = 6561     # R/s3tokenizer.R:7 (ids >= this are the start / stop / padding specials)
+
+
+def drop_invalid_tokens(tokens, speech_vocab_size: int = SPEECH_VOCAB_SIZE) -> np.ndarray:
+    """R/s3tokenizer.R:678-687: keep the ids below SPEECH_VOCAB_SIZE, order preserved (generate() applies it to
+    the T3 output before S3Gen, R/tts.R:366)."""
+    t = np.asarray(tokens, dtype=np.int64).reshape(-1)
+    return t[t < int(speech_vocab_size)]
+
+
+def split_sentences(text: str) -> List[str]:
+    """The sentence split of tts_chunked, R/tts.R:462: strsplit(text, "(?<=[.!?])\\s+", perl = TRUE)[[1]].
+    R's strsplit returns character(0) for "" and drops the empty piece after a match at the end of the string."""
+    import re
+    if text == "":
+        return []
+    parts = re.split(r"(?<=[.!?])\s+", text)
+    if parts and parts[-1] == "":
+        parts = parts[:-1]
+    return parts
+
+
+def tts_chunked(model: T3Model, text: str, cond: T3Cond, tokenize, chunk_size: int = 200, batched: bool = True,
+                drop_invalid: bool = True, **kw) -> dict:
+    """tts_chunked (R/tts.R:455-480) up to the speech tokens: the text is split into sentences exactly as the
+    reference does, every sentence is tokenised by `tokenize(sentence) -> text token ids` (the reference's BPE
+    tokenizer, or punc_norm + the GPT-2 tokenizer on Turbo: R/tts.R:278-285 -- host string work, out of scope
+    here), and the sentences go through T3 either as ONE batch (`batched`, the default: the sentences are
+    independent) or one after the other like the reference's loop (R/tts.R:466-474).  Both give
+    the same tokens: every sentence keeps its own RNG stream (seed, sentence index).  `chunk_size` is accepted
+    and unused, as in the reference.  Keyword arguments are those of t3_inference / t3_inference_turbo
+    (generate() passes cfg_weight, temperature, top_p, and top_k / repetition_penalty on Turbo: R/tts.R:303-360).
+    Returns {"sentences": [...], "speech_tokens": [array per sentence]} with drop_invalid_tokens applied
+    (R/tts.R:366); the waveform side (S3Gen, R/tts.R:392-412) stays with the reference."""
+    sentences = split_sentences(text)
+    if not sentences:
+        return {"sentences": [], "speech_tokens": []}
+    turbo = model.variant == _lib.VARIANT_TURBO
+    toks = [np.asarray(tokenize(s), dtype=np.int32).reshape(-1) for s in sentences]
+    fn = t3_inference_turbo_batch if turbo else t3_inference_batch
+    if batched:
+        out = fn(model, [cond] * len(sentences), toks, **kw)
+    else:
+        out = [fn(model, [cond], [t], first_utterance_id=i, **kw)[0] for i, t in enumerate(toks)]
+    if drop_invalid:
+        out = [drop_invalid_tokens(t) for t in out]
+    return {"sentences": sentences, "speech_tokens": out}
+
+
 class Session:
     """The decode loop in pieces (t3mi_session_*): prefill once, then enqueue steps.
     Used by bench.py (timed region = decode steps only) and by the parity tests
@@ -334,13 +387,13 @@ class Session:
                  min_p: float = 0.05, repetition_penalty: float = 1.2, sampler: int = _lib.SAMPLER_R,
                  max_cache_len: int = 0, seed: int = 0, mask_stop: bool = False,
                  forced: Optional[np.ndarray] = None, device_ptrs: Optional[Sequence[Tuple[int, int]]] = None,
-                 top_k: int = 0):
+                 top_k: int = 0, first_utterance_id: int = 0):
         self.model = model
         L = model._lib
         if model.variant == _lib.VARIANT_TURBO:
             sampler, cfg_weight, min_p = _lib.SAMPLER_TURBO, 0.0, 0.0
         p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
-                    sampler, max_cache_len, seed, mask_stop, top_k)
+                    sampler, max_cache_len, seed, mask_stop, top_k, first_utterance_id)
         if device_ptrs is not None:
             # [(device_address, s0)] of prompts already resident in HBM, each [rpu, s0, d] float32
             self.n_utt = len(device_ptrs)

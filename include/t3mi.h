@@ -61,9 +61,13 @@ typedef struct t3mi_params {
     int32_t stop_token;          /* stop_speech_token 6562 (R/t3.R:20)                      */
     int32_t sampler;             /* T3MI_SAMPLER_*                                          */
     int32_t top_k;               /* turbo only (R/t3.R:1579), 0 = off                       */
-    int32_t max_cache_len;       /* 0 = prompt + max_new_tokens (R path, Q13); else cap (cpp: 350) */
+    int32_t max_cache_len;       /* 0 = prompt + max_new_tokens (R path, Q13); else cap (cpp: 350): utterance u then
+                                    generates at most min(max_new_tokens, max_cache_len - s0[u] - 1) (R/t3.R:996) */
     int32_t mask_stop;           /* 1 = never emit stop_token (fixed-length bench workloads) */
     uint64_t seed;               /* stream of the build's counter RNG (libtorch's is not reproducible) */
+    int64_t first_utterance_id;  /* global index of utterance 0 of this call: utterance u draws from the RNG stream
+                                    (seed, first_utterance_id + u), so a batch split over calls / ranks samples the
+                                    same tokens as the unsplit batch; 0 for a single call            */
 } t3mi_params;
 
 typedef struct t3mi_info {
@@ -99,7 +103,9 @@ int t3mi_get_info(const t3mi_model* m, t3mi_info* info);
  * == t3_inference (R/t3.R:461-605) after prepare_input_embeds, and == t3_inference_cpp's
  * prefill + .Call("cpp_t3_decode") (R/t3.R:987-1036).
  *   embeds : host float32 [rows, s0, d_model], row-major (rows = 2 with CFG: cond, uncond)
- *   out    : receives 0-indexed token ids INCLUDING the stop token if hit (Q14); cap >= max_new_tokens
+ *   out    : receives 0-indexed token ids INCLUDING the stop token if hit (Q14); cap >= max_new_tokens, and
+ *            cap >= max_new_tokens + 1 on the Turbo variant, which samples one token from the prefill logits and
+ *            then up to max_new_tokens more (R/t3.R:1614-1658); a smaller cap is rejected with T3MI_ERR_ARG
  * Returns T3MI_OK, T3MI_WARN_CACHE_FULL, or an error. */
 int t3mi_generate(t3mi_model* m, const float* embeds, int rows, int s0, const t3mi_params* p,
                   int32_t* out, int32_t cap, int32_t* n_out);
@@ -135,6 +141,18 @@ int t3mi_prompt_shape(t3mi_model* m, const t3mi_cond* cond, int n_text, float cf
  * host array out[rows, s0, d_model] (parity hook; the generate calls below keep the prompt in HBM). */
 int t3mi_prepare_input_embeds(t3mi_model* m, const t3mi_cond* cond, const int32_t* text_tokens, int n_text,
                               float cfg_weight, int32_t start_token, float* out, size_t cap_floats);
+/* t3mi_prepare_input_embeds for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO counterpart in the reference.  Same inputs and same values as
+ * t3mi_prepare_input_embeds, but (i) the result [rows, s0, d_model] is written to the CALLER'S DEVICE buffer
+ * `out_device` (on the model's GPU) and (ii) all working memory (uploaded ids, speaker vector, the perceiver's
+ * intermediate rows) lives in a fixed 8.02 MiB array inside the library's code object, one copy per GPU, held until the
+ * process ends: the call makes no hipMalloc / hipFree.  Limits (T3MI_ERR_ARG beyond them, with the numbers in the
+ * message): n_cond + n_text + 3 <= 4096 ids, speaker embedding <= 1024 floats, (4 * max(n_cond, n_query) + 4 * n_query)
+ * * d_model <= 2,097,152 floats (e.g. d_model 1024, 32 queries: up to 480 conditioning tokens).  Nothing in the array
+ * needs to start at zero (every row is written before it is read).  All calls on one GPU share that GPU's array: calls
+ * that overlap on one GPU race; the call returns after the model's stream has drained. */
+int t3mi_prepare_input_embeds_static(t3mi_model* m, const t3mi_cond* cond, const int32_t* text_tokens, int n_text,
+                                     float cfg_weight, int32_t start_token, float* out_device, size_t cap_floats);
 /* t3_inference(model, cond, text_tokens, ...) (R/t3.R:461-605) / t3_inference_turbo (R/t3.R:1578-1677):
  * prompt built on device, then the same loop as t3mi_generate. */
 int t3mi_generate_tokens(t3mi_model* m, const t3mi_cond* cond, const int32_t* text_tokens, int n_text,

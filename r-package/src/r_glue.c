@@ -88,14 +88,16 @@ static void fill_params(SEXP cfg, t3mi_params* p) {
     p->top_k = (int32_t)cfg_real(cfg, "top_k", 0, 0);                 /* Turbo (.turbo_sample_token, R/t3.R:1688-1742) */
     p->max_cache_len = (int32_t)cfg_real(cfg, "max_cache_len", 0, 0);
     p->seed = (uint64_t)cfg_real(cfg, "seed", 0, 0);
+    p->first_utterance_id = (int64_t)cfg_real(cfg, "first_utterance_id", 0, 0);
 }
 
-/* R arrays are column-major doubles: embeds[r, t, k] sits at r + rows*(t + s0*k). */
+/* R arrays are column-major doubles: embeds[r, t, k] sits at r + rows*(t + s0*k).  Returns NULL for a wrong shape or
+ * when out of memory -- never longjmps, so a caller that already holds C allocations can free them first. */
 static float* to_row_major(SEXP embeds, int rows, int s0, int d) {
     const R_xlen_t n = (R_xlen_t)rows * s0 * d;
-    if (!Rf_isReal(embeds) || Rf_xlength(embeds) != n) Rf_error("t3mi: embeds must be a numeric [rows, S0, d] array");
+    if (rows <= 0 || s0 <= 0 || d <= 0 || !Rf_isReal(embeds) || Rf_xlength(embeds) != n) return NULL;
     float* out = (float*)malloc((size_t)n * sizeof(float));
-    if (!out) Rf_error("t3mi: out of memory");
+    if (!out) return NULL;
     const double* src = REAL(embeds);
     for (int r = 0; r < rows; r++)
         for (int t = 0; t < s0; t++)
@@ -117,11 +119,12 @@ SEXP t3mi_r_generate(SEXP model, SEXP embeds, SEXP dims, SEXP cfg) {
     const int cap = (p.max_new_tokens > 0 ? p.max_new_tokens : 1) + 1;   /* Turbo returns up to max_tokens + 1 ids */
     int32_t* out = (int32_t*)malloc((size_t)cap * sizeof(int32_t));
     int32_t n = 0;
-    int rc = out ? t3mi_generate(m, e, rows, s0, &p, out, cap, &n) : T3MI_ERR_ARG;
+    const int bad_args = !e || !out;
+    int rc = bad_args ? T3MI_ERR_ARG : t3mi_generate(m, e, rows, s0, &p, out, cap, &n);
     free(e);
     if (rc < 0) { /* free C state first, then longjmp (SURVEY §8b "Errors") */
         free(out);
-        Rf_error("t3mi_generate: %s", t3mi_last_error());
+        Rf_error("t3mi_generate: %s", bad_args ? "embeds must be a numeric [rows, S0, d] array" : t3mi_last_error());
     }
     SEXP res = PROTECT(Rf_allocVector(INTSXP, n));
     for (int i = 0; i < n; i++) INTEGER(res)[i] = (int)out[i];
@@ -152,6 +155,7 @@ SEXP t3mi_r_generate_batch(SEXP model, SEXP embeds_list, SEXP dims, SEXP cfg) {
         if (dm[u] != rows || dm[2 * n_utt + u] != d) { rc = T3MI_ERR_ARG; break; }
         s0[u] = dm[n_utt + u];
         e[u] = to_row_major(VECTOR_ELT(embeds_list, u), rows, s0[u], d);
+        if (!e[u]) rc = T3MI_ERR_ARG;   /* wrong shape / out of memory: everything is freed below before Rf_error */
     }
     if (rc == T3MI_OK)
         rc = t3mi_generate_batch(m, n_utt, rows, (const float* const*)e, s0, &p, out, cap, n_out);
