@@ -724,7 +724,7 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     T* tl = reinterpret_cast<T*>(tl_raw);   // [2][kRows][LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = lane & 15, g = lane >> 4;
-    const int tile = blockIdx.x, m0 = blockIdx.y * 128, kz = blockIdx.z;
+    const int tile = blockIdx.x, m0 = blockIdx.y * (32 * AP), kz = blockIdx.z;
     const int K = a.K;
     // steps of this block.  SC > 0: known at compile time (the decode shapes: 8 or 4 steps), so that every `s < S`
     // below folds away -- with run-time conditions around the ring refills the compiler waits for vmcnt(0) in every
@@ -1061,6 +1061,38 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(float* __restrict__ 
     y[o] = resid != nullptr ? __fadd_rn(r, v) : v;
 }
 
+// rows per block of gemm_rows_kernel (32 * AP) for a launch of M rows (bf16 operands).  A block's time is mostly fixed
+// cost plus LDS traffic per step (32 * AP activation rows + 32 weight rows written, the fragments read back), so with
+// <= 128 rows smaller row chunks beat one 128-row chunk where the launch has few feature tiles: twice the blocks, 88
+// instead of 136 KB of LDS traffic per step each.  Measured at 128 rows over a 400-step session (step 2.153 ms with
+// 128-row chunks everywhere): qkv and gate_up in 64-row chunks 2.051 ms, o_proj (K-split, 2 steps per block) in 32-row
+// chunks as well 2.020 ms; 32-row chunks for qkv (2.059) or gate_up (2.082) and smaller chunks for down (2.023-2.099)
+// do not pay.  The results are bit-identical (a row's sums do not depend on its chunk).
+template <int EPI>
+inline int rows_chunk_ap(int M, int K) {
+    if (M <= 32) return 1;
+    if (M > 128) return 4;
+    if (EPI == EPI_RESID) return K <= 1024 ? 1 : (M <= 64 ? 2 : 4);
+    return 2;
+}
+
+template <int EPI, typename T, int SC>
+void launch_rows_ap(const GemmArgs& a, int ap, int tiles, int ks, hipStream_t s) {
+    constexpr int row_b = (128 + 8) * 2;   // LDS row stride in bytes (bf16 and fp32 alike: 256 B of data + 16 B)
+    const dim3 block(512);
+    if constexpr (sizeof(T) == 2) {
+        if (ap == 1) {
+            hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, SC, 1>), dim3(tiles, (a.M + 31) / 32, ks), block, 2 * 64 * row_b, s, a);
+            return;
+        }
+        if (ap == 2) {
+            hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, SC, 2>), dim3(tiles, (a.M + 63) / 64, ks), block, 2 * 96 * row_b, s, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, SC, 4>), dim3(tiles, (a.M + 127) / 128, ks), block, 2 * 160 * row_b, s, a);
+}
+
 template <int EPI, typename T>
 hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s) {
     constexpr int KC = 16 * (16 / (int)sizeof(T));   // the kernel's step: 128 (bf16) or 64 (fp32) k
@@ -1076,7 +1108,7 @@ hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s) {
                (size_t)(2 * ks) * a.M * a.N <= a.part_floats)
             ks *= 2;
     }
-    constexpr int lds = 2 * 160 * (128 + 8) * 2;   // two step tiles: 87,040 B
+    constexpr int lds = 2 * 160 * (128 + 8) * 2;   // two step tiles of the 128-row form: 87,040 B
     constexpr int SC16 = sizeof(T) == 4 ? 16 : 0;  // fp32 operands: 64-k steps, K = 1024 is 16 of them
     // the attribute belongs to the (kernel, device) pair: one flag per EPI instantiation and device
     static bool attr_done[64] = {};   // (static in a function template: one array per <EPI, T>)
@@ -1084,11 +1116,11 @@ hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s) {
     hipError_t ed = hipGetDevice(&dev);
     if (ed != hipSuccess) return ed;
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        const void* fns[5] = {reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, 0>),
-                              reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, 8>),
-                              reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, 4>),
-                              reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, 2>),
-                              reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, SC16>)};
+        const void* fns[5] = {reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, 0, 4>),
+                              reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, 8, 4>),
+                              reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, 4, 4>),
+                              reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, 2, 4>),
+                              reinterpret_cast<const void*>(gemm_rows_kernel<EPI, T, SC16, 4>)};
         for (const void* fn : fns) {
             hipError_t e0 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e0 != hipSuccess) return e0;
@@ -1096,19 +1128,12 @@ hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s) {
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const int steps = a.K / KC / ks;
-    const dim3 grid(tiles, chunks, ks), block(512);
-    // <= 32 rows of bf16 operands (a handful of utterances, Turbo's batch of sentences): one staging pass
-    if (sizeof(T) == 2 && a.M <= 32 && (steps == 8 || steps == 4 || steps == 2)) {
-        constexpr int lds1 = 2 * 64 * (128 + 8) * 2;
-        constexpr int AP1 = sizeof(T) == 2 ? 1 : 4;
-        if (steps == 8) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 8, AP1>), dim3(tiles, 1, ks), block, lds1, s, a);
-        else if (steps == 4) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 4, AP1>), dim3(tiles, 1, ks), block, lds1, s, a);
-        else hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 2, AP1>), dim3(tiles, 1, ks), block, lds1, s, a);
-    } else if (steps == 8) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 8>), grid, block, lds, s, a);
-    else if (steps == 4) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 4>), grid, block, lds, s, a);
-    else if (steps == 2) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 2>), grid, block, lds, s, a);
-    else if (sizeof(T) == 4 && steps == 16) hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, SC16>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((gemm_rows_kernel<EPI, T, 0>), grid, block, lds, s, a);
+    const int ap = sizeof(T) == 2 ? rows_chunk_ap<EPI>(a.M, a.K) : 4;
+    if (steps == 8) launch_rows_ap<EPI, T, 8>(a, ap, tiles, ks, s);
+    else if (steps == 4) launch_rows_ap<EPI, T, 4>(a, ap, tiles, ks, s);
+    else if (steps == 2) launch_rows_ap<EPI, T, 2>(a, ap, tiles, ks, s);
+    else if (sizeof(T) == 4 && steps == 16) launch_rows_ap<EPI, T, SC16>(a, 4, tiles, ks, s);
+    else launch_rows_ap<EPI, T, 0>(a, 4, tiles, ks, s);
     hipError_t e = hipGetLastError();
     if (a.ks_out != nullptr) *a.ks_out = ks;
     if (e != hipSuccess || ks == 1) return e;
