@@ -3,7 +3,7 @@
 
 Only the T3 decode hot path lives here; the rest of the reference
 (tokenizers, voice encoders, S3Gen, vocoder, download) is out of scope."""
-from .t3 import (SPEECH_VOCAB_SIZE, Session, T3Cond, T3Model, drop_invalid_tokens, load_t3, load_t3_turbo,  # noqa: F401
+from .t3 import (SPEECH_VOCAB_SIZE, Session, T3Cond, T3Model, drop_invalid_tokens, inspect_checkpoint, load_t3, load_t3_turbo,  # noqa: F401
                  prepare_input_embeds, split_sentences, t3_cond, t3_inference, t3_inference_batch, t3_inference_cpp,
                  t3_inference_traced, t3_inference_turbo, t3_inference_turbo_batch, tts_chunked)
 

@@ -14,6 +14,7 @@ ERR_ARG, ERR_IO, ERR_HIP, ERR_STATE = -1, -2, -3, -4
 WARN_CACHE_FULL = 1
 VARIANT_LLAMA, VARIANT_TURBO = 0, 1
 W_F32, W_BF16 = 0, 1
+CACHE_NONE, CACHE_WRITTEN, CACHE_USED, CACHE_REPLACED = 0, 1, 2, 3
 SAMPLER_R, SAMPLER_CPP, SAMPLER_TURBO = 0, 1, 2
 
 
@@ -39,7 +40,8 @@ class Params(C.Structure):
 class Info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("variant", "n_layers", "d_model", "n_heads", "head_dim", "d_ff", "vocab", "max_pos",
-                 "wdtype", "device")] + [("weight_bytes", C.c_int64)]
+                 "wdtype", "device")] + [("weight_bytes", C.c_int64), ("cache_state", C.c_int32),
+                                         ("has_prompt_tensors", C.c_int32)]
 
 
 class Cond(C.Structure):
@@ -63,6 +65,8 @@ SYMBOLS = {
     "t3mi_last_error": (C.c_char_p, []),
     "t3mi_device_count": (C.c_int, []),
     "t3mi_open": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_H)]),
+    "t3mi_open_cached": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_H)]),
+    "t3mi_inspect": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(Info)]),
     "t3mi_close": (C.c_int, [_H]),
     "t3mi_get_info": (C.c_int, [_H, C.POINTER(Info)]),
     "t3mi_generate": (C.c_int, [_H, _FP, C.c_int, C.c_int, C.POINTER(Params), _IP, C.c_int32, _IP]),

@@ -74,7 +74,7 @@ struct Item {
 
 void prompt_free(PromptModel* pm) { delete pm; }
 
-int prompt_load(const SafeTensorsFile& st, int variant, int d, PromptModel** out, std::string& err) {
+int prompt_load(const SafeTensorsFile& st, int variant, int d, PromptModel** out, std::string& err, bool validate_only) {
     *out = nullptr;
     const StTensor* te = st.find("text_emb.weight");
     const StTensor* sw = st.find("cond_enc.spkr_enc.weight");
@@ -135,8 +135,13 @@ int prompt_load(const SafeTensorsFile& st, int variant, int d, PromptModel** out
             err = std::string("prompt tensors: '") + it.name + "' is missing or has an unexpected shape";
             return T3MI_ERR_IO;
         }
+        if (t->dtype != StDtype::F32 && t->dtype != StDtype::F16 && t->dtype != StDtype::BF16) {
+            err = std::string("prompt tensors: '") + it.name + "' is not a floating-point tensor (F32 / F16 / BF16)";
+            return T3MI_ERR_IO;
+        }
         total += ((size_t)t->numel() + 63) / 64 * 64;   // 256-byte aligned slots
     }
+    if (validate_only) return 0;
     PHIP(pm->w.reserve(total * 4));
     float* dst = pm->w.as<float>();
     std::vector<float> host;

@@ -33,7 +33,8 @@ struct PromptCond {
 };
 
 // 0 = loaded, 1 = the checkpoint has no prompt tensors (*out = nullptr, not an error), < 0 = malformed (err filled)
-int prompt_load(const SafeTensorsFile& st, int variant, int d, PromptModel** out, std::string& err);
+// validate_only: check names, shapes and dtypes, touch no device (*out stays nullptr)
+int prompt_load(const SafeTensorsFile& st, int variant, int d, PromptModel** out, std::string& err, bool validate_only = false);
 void prompt_free(PromptModel* pm);
 // start of a batch of prompt_build calls: sizes the staging arenas for `total_ids` token ids (conditioning + text +
 // start / stop + BOS, summed over the batch) and n_utt speaker vectors.  The stream must be drained (the previous

@@ -5,6 +5,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cerrno>
+#include <cstdint>
 #include <cstring>
 
 namespace t3mi {
@@ -67,7 +69,10 @@ struct Cur {
         }
         if (p >= e || *p < '0' || *p > '9') return fail("expected integer");
         v = 0;
-        while (p < e && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
+        while (p < e && *p >= '0' && *p <= '9') {
+            if (v > (INT64_MAX - 9) / 10) return fail("integer out of range");
+            v = v * 10 + (*p++ - '0');
+        }
         if (neg) v = -v;
         return true;
     }
@@ -165,6 +170,7 @@ bool SafeTensorsFile::open(const std::string& path, std::string& err) {
         return false;
     }
     map_len_ = (size_t)st.st_size;
+    mtime_ns_ = (int64_t)st.st_mtim.tv_sec * 1000000000LL + (int64_t)st.st_mtim.tv_nsec;
     map_ = mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd_, 0);
     if (map_ == MAP_FAILED) {
         err = "mmap failed for '" + path + "'";
@@ -208,6 +214,7 @@ bool SafeTensorsFile::open(const std::string& path, std::string& err) {
                         for (;;) {
                             int64_t v;
                             if (!c.integer(v)) return false;
+                            if (v < 0) return c.fail("negative extent in a shape");
                             t.shape.push_back(v);
                             if (c.eat(',')) continue;
                             if (c.eat(']')) break;
@@ -233,6 +240,16 @@ bool SafeTensorsFile::open(const std::string& path, std::string& err) {
             }
             t.data = data0 + off0;
             t.nbytes = (size_t)(off1 - off0);
+            {
+                int64_t n = 1;
+                for (int64_t ext : t.shape) {
+                    if (ext != 0 && n > (int64_t(1) << 62) / ext) {
+                        err = "tensor '" + name + "': shape overflows";
+                        return false;
+                    }
+                    n *= ext;
+                }
+            }
             const size_t es = dtype_size(t.dtype);
             if (es && (size_t)t.numel() * es != t.nbytes) {
                 err = "tensor '" + name + "': shape does not match byte size";

@@ -23,7 +23,7 @@ struct StTensor {
     std::vector<int64_t> shape;
     const uint8_t* data = nullptr;   // points into the mmap
     size_t nbytes = 0;
-    int64_t numel() const {
+    int64_t numel() const {   // shapes are validated at open(): no negative extent, product below 2^62
         int64_t n = 1;
         for (auto s : shape) n *= s;
         return n;
@@ -41,6 +41,8 @@ public:
     bool open(const std::string& path, std::string& err);
     const StTensor* find(const std::string& name) const;
     const std::map<std::string, StTensor>& tensors() const { return tensors_; }
+    size_t file_size() const { return map_len_; }
+    int64_t mtime_ns() const { return mtime_ns_; }
 
     // Convert tensor `t` (F32/F16/BF16) to float32 into dst[numel].
     static bool to_f32(const StTensor& t, float* dst, std::string& err);
@@ -49,6 +51,7 @@ private:
     void* map_ = nullptr;
     size_t map_len_ = 0;
     int fd_ = -1;
+    int64_t mtime_ns_ = 0;
     std::map<std::string, StTensor> tensors_;
 };
 

@@ -15,6 +15,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -144,6 +148,7 @@ struct t3mi_model {
     const float* head_b_f = nullptr;
     int64_t weight_bytes = 0;
     std::unique_ptr<Session> sess;
+    int cache_state = 0;                   // T3MI_CACHE_*: what t3mi_open_cached did with the packed bf16 file
     void* static_scratch = nullptr;        // this GPU's copy of the file-scope `scratch` array (hipGetSymbolAddress at open)
     t3mi::PromptModel* prompt = nullptr;   // text_emb / cond_enc.* tensors (nullptr: decode-only checkpoint)
     DevBuf prompt_buf;                     // prompts built on device, alive until the next build
@@ -200,12 +205,158 @@ int ensure_rope(t3mi_model* m, int rows) {
     return T3MI_OK;
 }
 
+// ---- checkpoint validation (no device): every tensor the loaders below fetch, by name and shape ------------------
+struct CkptDims {
+    int L = 0, d = 0, H = 0, F = 0, V = 0, max_pos = 0;
+};
+struct TensorSpec {
+    std::string name;
+    int64_t d0, d1;   // d1 < 0: one-dimensional
+};
+
+int check_specs(const t3mi::SafeTensorsFile& st, const std::vector<TensorSpec>& specs) {
+    for (const TensorSpec& sp : specs) {
+        const t3mi::StTensor* t = st.find(sp.name);
+        if (!t) return fail(T3MI_ERR_IO, "checkpoint has no tensor '" + sp.name + "'");
+        const bool ok = (sp.d1 < 0) ? (t->shape.size() == 1 && t->shape[0] == sp.d0)
+                                    : (t->shape.size() == 2 && t->shape[0] == sp.d0 && t->shape[1] == sp.d1);
+        if (!ok) return fail(T3MI_ERR_IO, "tensor '" + sp.name + "' has an unexpected shape");
+        if (t->dtype != t3mi::StDtype::F32 && t->dtype != t3mi::StDtype::F16 && t->dtype != t3mi::StDtype::BF16)
+            return fail(T3MI_ERR_IO, "tensor '" + sp.name + "' is not a floating-point tensor (F32 / F16 / BF16)");
+    }
+    return T3MI_OK;
+}
+
+// shapes of the Llama-backbone checkpoint from the file itself (R/llama.R:20-45 for the 520M model), then every tensor
+// of R/llama.R:566-607 / R/t3.R:1065-1097 that the decode path reads
+int llama_dims(const t3mi::SafeTensorsFile& st, CkptDims& c) {
+    const t3mi::StTensor* q0 = st.find("tfmr.layers.0.self_attn.q_proj.weight");
+    const t3mi::StTensor* g0 = st.find("tfmr.layers.0.mlp.gate_proj.weight");
+    const t3mi::StTensor* hd = st.find("speech_head.weight");
+    const t3mi::StTensor* pe = st.find("speech_pos_emb.emb.weight");
+    if (!q0 || !g0 || !hd || !pe || q0->shape.size() != 2 || g0->shape.size() != 2 || hd->shape.size() != 2 ||
+        pe->shape.size() != 2)
+        return fail(T3MI_ERR_IO, "checkpoint lacks the T3 Llama tensors (tfmr.layers.0.*, speech_head, speech_pos_emb)");
+    if (q0->shape[1] <= 0 || q0->shape[1] > (1 << 20) || g0->shape[0] <= 0 || g0->shape[0] > (1 << 24) || hd->shape[0] <= 0 ||
+        hd->shape[0] > (1 << 24) || pe->shape[0] <= 0 || pe->shape[0] > (1 << 24))
+        return fail(T3MI_ERR_IO, "checkpoint: implausible tensor extents");
+    c.d = (int)q0->shape[1];
+    c.F = (int)g0->shape[0];
+    c.V = (int)hd->shape[0];
+    c.max_pos = (int)pe->shape[0];
+    if (c.d % 64 || q0->shape[0] != c.d) return fail(T3MI_ERR_IO, "hidden size must be heads*64");
+    c.H = c.d / 64;
+    c.L = 0;
+    while (st.find("tfmr.layers." + std::to_string(c.L) + ".self_attn.q_proj.weight")) ++c.L;
+    const int64_t d = c.d, F = c.F, V = c.V;
+    std::vector<TensorSpec> sp;
+    for (int l = 0; l < c.L; ++l) {
+        const std::string p = "tfmr.layers." + std::to_string(l) + ".";
+        sp.push_back({p + "input_layernorm.weight", d, -1});
+        sp.push_back({p + "self_attn.q_proj.weight", d, d});
+        sp.push_back({p + "self_attn.k_proj.weight", d, d});
+        sp.push_back({p + "self_attn.v_proj.weight", d, d});
+        sp.push_back({p + "self_attn.o_proj.weight", d, d});
+        sp.push_back({p + "post_attention_layernorm.weight", d, -1});
+        sp.push_back({p + "mlp.gate_proj.weight", F, d});
+        sp.push_back({p + "mlp.up_proj.weight", F, d});
+        sp.push_back({p + "mlp.down_proj.weight", d, F});
+    }
+    sp.push_back({"tfmr.norm.weight", d, -1});
+    sp.push_back({"speech_head.weight", V, d});
+    sp.push_back({"speech_emb.weight", V, d});
+    sp.push_back({"speech_pos_emb.emb.weight", c.max_pos, d});
+    return check_specs(st, sp);
+}
+
+// Turbo (GPT-2 backbone): keys of R/t3.R:1508-1549, linear weights [out, in] as nn_linear holds them
+int turbo_dims(const t3mi::SafeTensorsFile& st, CkptDims& c) {
+    const t3mi::StTensor* qkv0 = st.find("tfmr.h.0.attn.c_attn.weight");
+    const t3mi::StTensor* fc0 = st.find("tfmr.h.0.mlp.c_fc.weight");
+    const t3mi::StTensor* hd = st.find("speech_head.weight");
+    if (!qkv0 || !fc0 || !hd || qkv0->shape.size() != 2 || fc0->shape.size() != 2 || hd->shape.size() != 2)
+        return fail(T3MI_ERR_IO, "checkpoint lacks the T3 Turbo tensors (tfmr.h.0.*, speech_head)");
+    if (qkv0->shape[1] <= 0 || qkv0->shape[1] > (1 << 20) || fc0->shape[0] <= 0 || fc0->shape[0] > (1 << 24) ||
+        hd->shape[0] <= 0 || hd->shape[0] > (1 << 24))
+        return fail(T3MI_ERR_IO, "checkpoint: implausible tensor extents");
+    c.d = (int)qkv0->shape[1];
+    if (qkv0->shape[0] != 3 * (int64_t)c.d)
+        return fail(T3MI_ERR_IO, "tfmr.h.0.attn.c_attn.weight must be [3*d, d] (nn_linear layout, R/t3.R:1220)");
+    c.F = (int)fc0->shape[0];
+    c.V = (int)hd->shape[0];
+    c.max_pos = 1 << 30;   // no learned speech position table on this path (R/t3.R:1628)
+    if (c.d % 64) return fail(T3MI_ERR_IO, "hidden size must be heads*64");
+    c.H = c.d / 64;
+    c.L = 0;
+    while (st.find("tfmr.h." + std::to_string(c.L) + ".attn.c_attn.weight")) ++c.L;
+    const int64_t d = c.d, F = c.F, V = c.V;
+    std::vector<TensorSpec> sp;
+    for (int l = 0; l < c.L; ++l) {
+        const std::string p = "tfmr.h." + std::to_string(l) + ".";
+        sp.push_back({p + "ln_1.weight", d, -1});
+        sp.push_back({p + "ln_1.bias", d, -1});
+        sp.push_back({p + "ln_2.weight", d, -1});
+        sp.push_back({p + "ln_2.bias", d, -1});
+        sp.push_back({p + "attn.c_attn.weight", 3 * d, d});
+        sp.push_back({p + "attn.c_attn.bias", 3 * d, -1});
+        sp.push_back({p + "attn.c_proj.weight", d, d});
+        sp.push_back({p + "attn.c_proj.bias", d, -1});
+        sp.push_back({p + "mlp.c_fc.weight", F, d});
+        sp.push_back({p + "mlp.c_fc.bias", F, -1});
+        sp.push_back({p + "mlp.c_proj.weight", d, F});
+        sp.push_back({p + "mlp.c_proj.bias", d, -1});
+    }
+    sp.push_back({"tfmr.ln_f.weight", d, -1});
+    sp.push_back({"tfmr.ln_f.bias", d, -1});
+    sp.push_back({"speech_head.weight", V, d});
+    sp.push_back({"speech_head.bias", V, -1});
+    sp.push_back({"speech_emb.weight", V, d});
+    return check_specs(st, sp);
+}
+
+// ---- packed bf16 weight cache ---------------------------------------------------------------------
+// The bf16 image of the streamed matrices (wbuf: 1.02 GB for the 520M model) exactly as the kernels read it, kept in a
+// side file so the next t3mi_open reads half the bytes and converts nothing.  The header ties it to its source file
+// (size + mtime in ns) and to the layout (variant, dims, version); anything that does not match, a short file or a
+// checksum mismatch means "no cache": the weights are converted from the checkpoint again and the file is rewritten.
+struct CacheHeader {
+    char magic[8];           // "T3MIW16\0"
+    uint32_t version, variant, n_layers, d, F, V;
+    uint64_t src_size;
+    int64_t src_mtime_ns;
+    uint64_t payload_bytes, checksum;
+};
+constexpr uint32_t kCacheVersion = 1;
+
+// four independent multiply-xor lanes over 32-byte groups (a single chain is latency-bound at ~1 GB/s; this runs at
+// memory speed), folded at the end; every byte and its position enter the result
+uint64_t payload_checksum(const uint8_t* p, size_t n) {
+    uint64_t h[4] = {0x9E3779B97F4A7C15ULL, 0xBF58476D1CE4E5B9ULL, 0x94D049BB133111EBULL, 0x2545F4914F6CDD1DULL};
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, p + i, 32);
+        for (int k = 0; k < 4; ++k) {
+            h[k] = (h[k] ^ w[k]) * 0x100000001B3ULL;
+            h[k] = (h[k] << 23) | (h[k] >> 41);
+        }
+    }
+    uint64_t r = n;
+    for (; i < n; ++i) r = (r ^ p[i]) * 0x100000001B3ULL;
+    for (int k = 0; k < 4; ++k) {
+        r = (r ^ h[k]) * 0xFF51AFD7ED558CCDULL;
+        r ^= r >> 33;
+    }
+    return r;
+}
+
 // ---- checkpoint -> HBM -----------------------------------------------------------------------
 struct Uploader {
     t3mi_model* m;
     const t3mi::SafeTensorsFile& st;
     std::vector<float> host;
     DevBuf stage;  // fp32 staging on device for the bf16 conversion
+    bool skip_w = false;   // the streamed matrices came from the packed cache: put_w only advances
 
     int get(const std::string& name, int64_t d0, int64_t d1, const t3mi::StTensor** out) {
         const t3mi::StTensor* t = st.find(name);
@@ -274,6 +425,7 @@ struct Uploader {
     }
     // streamed matrix in the model's weight dtype; dst points into wbuf
     int put_w(const std::string& name, int64_t d0, int64_t d1, void* dst) {
+        if (skip_w) return T3MI_OK;
         if (m->wdtype == T3MI_W_F32) return put_f32(name, d0, d1, static_cast<float*>(dst));
         const size_t n = (size_t)d0 * (size_t)d1;
         if (stage.bytes < n * 4) HIPCHK(stage.alloc(n * 4));
@@ -285,24 +437,78 @@ struct Uploader {
     }
 };
 
-int load_llama(t3mi_model* m, const t3mi::SafeTensorsFile& st) {
-    // infer shapes from the file (R/llama.R:20-45 for the 520M model)
-    const t3mi::StTensor* q0 = st.find("tfmr.layers.0.self_attn.q_proj.weight");
-    const t3mi::StTensor* g0 = st.find("tfmr.layers.0.mlp.gate_proj.weight");
-    const t3mi::StTensor* hd = st.find("speech_head.weight");
-    const t3mi::StTensor* pe = st.find("speech_pos_emb.emb.weight");
-    if (!q0 || !g0 || !hd || !pe || q0->shape.size() != 2 || g0->shape.size() != 2 || hd->shape.size() != 2 ||
-        pe->shape.size() != 2)
-        return fail(T3MI_ERR_IO, "checkpoint lacks the T3 Llama tensors (tfmr.layers.0.*, speech_head, speech_pos_emb)");
-    m->d = (int)q0->shape[1];
-    m->F = (int)g0->shape[0];
-    m->V = (int)hd->shape[0];
-    m->max_pos = (int)pe->shape[0];
-    if (m->d % 64 || q0->shape[0] != m->d) return fail(T3MI_ERR_IO, "hidden size must be heads*64");
-    m->H = m->d / 64;
-    int L = 0;
-    while (st.find("tfmr.layers." + std::to_string(L) + ".self_attn.q_proj.weight")) ++L;
-    m->n_layers = L;
+CacheHeader cache_header(const t3mi_model* m, const t3mi::SafeTensorsFile& st, size_t payload) {
+    CacheHeader h;
+    std::memset(&h, 0, sizeof(h));
+    std::memcpy(h.magic, "T3MIW16", 8);
+    h.version = kCacheVersion;
+    h.variant = (uint32_t)m->variant;
+    h.n_layers = (uint32_t)m->n_layers;
+    h.d = (uint32_t)m->d;
+    h.F = (uint32_t)m->F;
+    h.V = (uint32_t)m->V;
+    h.src_size = (uint64_t)st.file_size();
+    h.src_mtime_ns = st.mtime_ns();
+    h.payload_bytes = (uint64_t)payload;
+    return h;
+}
+
+// true: wbuf now holds the cached bf16 matrices.  false: no usable cache (m->cache_state says why); never an error.
+bool cache_read(t3mi_model* m, const t3mi::SafeTensorsFile& st, const char* cache_path, size_t payload) {
+    m->cache_state = T3MI_CACHE_NONE;
+    if (!cache_path || !cache_path[0] || m->wdtype != T3MI_W_BF16) return false;
+    m->cache_state = T3MI_CACHE_WRITTEN;   // provisional: no file yet
+    const int fd = ::open(cache_path, O_RDONLY);
+    if (fd < 0) return false;
+    m->cache_state = T3MI_CACHE_REPLACED;  // a file exists; anything wrong with it below means it is rewritten
+    struct stat sb;
+    bool ok = fstat(fd, &sb) == 0 && (uint64_t)sb.st_size == sizeof(CacheHeader) + (uint64_t)payload;   // not truncated, nothing appended
+    void* map = ok ? mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+    ::close(fd);
+    if (map == MAP_FAILED) return false;
+    const CacheHeader want = cache_header(m, st, payload);
+    CacheHeader got;
+    std::memcpy(&got, map, sizeof(got));
+    const uint64_t sum = got.checksum;
+    got.checksum = 0;
+    const uint8_t* body = static_cast<const uint8_t*>(map) + sizeof(CacheHeader);
+    ok = std::memcmp(&got, &want, sizeof(want)) == 0 && payload_checksum(body, payload) == sum;
+    if (ok) ok = hipMemcpy(m->wbuf.p, body, payload, hipMemcpyHostToDevice) == hipSuccess;   // straight from the page cache
+    munmap(map, (size_t)sb.st_size);
+    if (ok) m->cache_state = T3MI_CACHE_USED;
+    return ok;
+}
+
+// best effort: a cache that cannot be written (read-only directory, disk full) costs the next open the conversion
+void cache_write(t3mi_model* m, const t3mi::SafeTensorsFile& st, const char* cache_path, size_t payload) {
+    if (!cache_path || !cache_path[0] || m->wdtype != T3MI_W_BF16) return;
+    std::vector<uint8_t> buf(payload);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(buf.data(), m->wbuf.p, payload, hipMemcpyDeviceToHost) != hipSuccess) {
+        m->cache_state = T3MI_CACHE_NONE;
+        return;
+    }
+    CacheHeader h = cache_header(m, st, payload);
+    h.checksum = payload_checksum(buf.data(), payload);
+    const std::string tmp = std::string(cache_path) + ".tmp" + std::to_string((long long)getpid());
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    bool ok = f != nullptr;
+    if (ok) {
+        ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(buf.data(), 1, payload, f) == payload;
+        ok = (std::fclose(f) == 0) && ok;
+    }
+    if (ok) ok = std::rename(tmp.c_str(), cache_path) == 0;   // atomic: a reader never sees a half-written cache
+    if (!ok) {
+        std::remove(tmp.c_str());
+        m->cache_state = T3MI_CACHE_NONE;
+    }
+}
+
+int load_llama(t3mi_model* m, const t3mi::SafeTensorsFile& st, const char* cache_path) {
+    CkptDims cd;
+    int rc = llama_dims(st, cd);   // every name, shape and dtype is checked before the first allocation
+    if (rc) return rc;
+    m->d = cd.d; m->F = cd.F; m->V = cd.V; m->max_pos = cd.max_pos; m->H = cd.H; m->n_layers = cd.L;
+    const int L = cd.L;
     const size_t d = m->d, F = m->F, V = m->V;
     const size_t es = m->wdtype == T3MI_W_BF16 ? 2 : 4;
     const size_t per_layer = (3 * d * d + d * d + 2 * F * d + d * F) * es;
@@ -314,10 +520,10 @@ int load_llama(t3mi_model* m, const t3mi::SafeTensorsFile& st) {
     m->weight_bytes = (int64_t)total + (int64_t)(2 * d * L + d) * 4;
 
     Uploader up{m, st, {}, {}};
+    up.skip_w = cache_read(m, st, cache_path, total);
     char* w = m->wbuf.as<char>();
     float* sm = m->small.as<float>();
     m->layers.resize(L);
-    int rc;
     for (int l = 0; l < L; ++l) {
         const std::string p = "tfmr.layers." + std::to_string(l) + ".";
         LayerW& lw = m->layers[l];
@@ -352,28 +558,18 @@ int load_llama(t3mi_model* m, const t3mi::SafeTensorsFile& st) {
     if ((rc = up.put_w("speech_head.weight", V, d, w))) return rc;
     if ((rc = up.put_f32("speech_emb.weight", V, d, m->emb.as<float>()))) return rc;
     if ((rc = up.put_f32("speech_pos_emb.emb.weight", m->max_pos, d, m->pos_emb.as<float>()))) return rc;
+    if (!up.skip_w) cache_write(m, st, cache_path, total);
     return T3MI_OK;
 }
 
 // Turbo T3: GPT-2 medium backbone.  Keys and [out, in] linear layout as load_t3_turbo_weights copies them
 // into nn_linear parameters (R/t3.R:1489-1551); tfmr.wpe / text_emb / cond_enc are not on the decode path.
-int load_turbo(t3mi_model* m, const t3mi::SafeTensorsFile& st) {
-    const t3mi::StTensor* qkv0 = st.find("tfmr.h.0.attn.c_attn.weight");
-    const t3mi::StTensor* fc0 = st.find("tfmr.h.0.mlp.c_fc.weight");
-    const t3mi::StTensor* hd = st.find("speech_head.weight");
-    if (!qkv0 || !fc0 || !hd || qkv0->shape.size() != 2 || fc0->shape.size() != 2 || hd->shape.size() != 2)
-        return fail(T3MI_ERR_IO, "checkpoint lacks the T3 Turbo tensors (tfmr.h.0.*, speech_head)");
-    m->d = (int)qkv0->shape[1];
-    if (qkv0->shape[0] != 3 * (int64_t)m->d)
-        return fail(T3MI_ERR_IO, "tfmr.h.0.attn.c_attn.weight must be [3*d, d] (nn_linear layout, R/t3.R:1220)");
-    m->F = (int)fc0->shape[0];
-    m->V = (int)hd->shape[0];
-    m->max_pos = 1 << 30;   // no learned speech position table on this path (R/t3.R:1628)
-    if (m->d % 64) return fail(T3MI_ERR_IO, "hidden size must be heads*64");
-    m->H = m->d / 64;
-    int L = 0;
-    while (st.find("tfmr.h." + std::to_string(L) + ".attn.c_attn.weight")) ++L;
-    m->n_layers = L;
+int load_turbo(t3mi_model* m, const t3mi::SafeTensorsFile& st, const char* cache_path) {
+    CkptDims cd;
+    int rc = turbo_dims(st, cd);
+    if (rc) return rc;
+    m->d = cd.d; m->F = cd.F; m->V = cd.V; m->max_pos = cd.max_pos; m->H = cd.H; m->n_layers = cd.L;
+    const int L = cd.L;
     const size_t d = m->d, F = m->F, V = m->V;
     const size_t es = m->wdtype == T3MI_W_BF16 ? 2 : 4;
     const size_t per_layer = (3 * d * d + d * d + F * d + d * F) * es;
@@ -387,10 +583,10 @@ int load_turbo(t3mi_model* m, const t3mi::SafeTensorsFile& st) {
     m->weight_bytes = (int64_t)total + (int64_t)small_total * 4;
 
     Uploader up{m, st, {}, {}};
+    up.skip_w = cache_read(m, st, cache_path, total);
     char* w = m->wbuf.as<char>();
     float* sm = m->small.as<float>();
     m->layers.resize(L);
-    int rc;
     std::vector<float> bln;
     for (int l = 0; l < L; ++l) {
         const std::string p = "tfmr.h." + std::to_string(l) + ".";
@@ -450,6 +646,7 @@ int load_turbo(t3mi_model* m, const t3mi::SafeTensorsFile& st) {
     m->head_b_f = sm + V;
     if ((rc = up.put_folded_bias("speech_head.weight", "speech_head.bias", V, d, bln, sm, sm + V))) return rc;
     if ((rc = up.put_f32("speech_emb.weight", V, d, m->emb.as<float>()))) return rc;
+    if (!up.skip_w) cache_write(m, st, cache_path, total);
     return T3MI_OK;
 }
 
@@ -804,7 +1001,38 @@ int t3mi_device_count(void) {
     return n;
 }
 
+int t3mi_inspect(const char* path, int variant, t3mi_info* info) {
+    if (!path || !info) return fail(T3MI_ERR_ARG, "t3mi_inspect: null argument");
+    if (variant != T3MI_VARIANT_LLAMA && variant != T3MI_VARIANT_TURBO)
+        return fail(T3MI_ERR_ARG, "t3mi_inspect: variant must be T3MI_VARIANT_LLAMA or T3MI_VARIANT_TURBO");
+    t3mi::SafeTensorsFile st;
+    std::string err;
+    if (!st.open(path, err)) return fail(T3MI_ERR_IO, err);
+    CkptDims c;
+    int rc = variant == T3MI_VARIANT_TURBO ? turbo_dims(st, c) : llama_dims(st, c);
+    if (rc) return rc;
+    t3mi::PromptModel* pm = nullptr;
+    const int prc = t3mi::prompt_load(st, variant, c.d, &pm, err, /*validate_only=*/true);
+    if (prc < 0) return fail(prc, err);
+    std::memset(info, 0, sizeof(*info));
+    info->variant = variant;
+    info->n_layers = c.L;
+    info->d_model = c.d;
+    info->n_heads = c.H;
+    info->head_dim = 64;
+    info->d_ff = c.F;
+    info->vocab = c.V;
+    info->max_pos = c.max_pos;
+    info->device = -1;
+    info->has_prompt_tensors = prc == 0 ? 1 : 0;
+    return T3MI_OK;
+}
+
 int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model** out) {
+    return t3mi_open_cached(path, variant, device, wdtype, nullptr, out);
+}
+
+int t3mi_open_cached(const char* path, int variant, int device, int wdtype, const char* cache_path, t3mi_model** out) {
     if (!path || !out) return fail(T3MI_ERR_ARG, "t3mi_open: null argument");
     *out = nullptr;
     if (variant != T3MI_VARIANT_LLAMA && variant != T3MI_VARIANT_TURBO)
@@ -839,7 +1067,7 @@ int t3mi_open(const char* path, int variant, int device, int wdtype, t3mi_model*
     HIPCHK(t3k::init_device());
     HIPCHK(static_scratch(device, &m->static_scratch));   // once per device, with that device current
     HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-    int rc = variant == T3MI_VARIANT_TURBO ? load_turbo(m.get(), st) : load_llama(m.get(), st);
+    int rc = variant == T3MI_VARIANT_TURBO ? load_turbo(m.get(), st, cache_path) : load_llama(m.get(), st, cache_path);
     if (rc) {
         (void)hipStreamDestroy(m->stream);
         return rc;
@@ -886,6 +1114,8 @@ int t3mi_get_info(const t3mi_model* m, t3mi_info* info) {
     info->wdtype = m->wdtype;
     info->device = m->device;
     info->weight_bytes = m->weight_bytes;
+    info->cache_state = m->cache_state;
+    info->has_prompt_tensors = m->prompt != nullptr ? 1 : 0;
     return T3MI_OK;
 }
 

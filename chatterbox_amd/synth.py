@@ -170,18 +170,45 @@ def synth_embeds(rows: int, s0: int, d: int, seed: int) -> np.ndarray:
     return (rng.standard_normal((rows, s0, d), dtype=F32) * F32(0.53)).astype(F32)
 
 
-def write_safetensors(weights: Dict[str, np.ndarray], path: str) -> str:
+def to_bf16_bits(a: np.ndarray) -> np.ndarray:
+    """float32 -> bf16 bit patterns (uint16), round to nearest even, NaN kept quiet."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u.astype(np.uint64) + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    nan = (u & 0x7FFFFFFF) > 0x7F800000
+    r[nan] = ((u[nan] >> 16) | 0x40).astype(np.uint16)
+    return r
+
+
+def bf16_round(a: np.ndarray) -> np.ndarray:
+    """float32 values rounded to bf16 precision (as float32)."""
+    return (to_bf16_bits(a).astype(np.uint32) << 16).view(np.float32).reshape(a.shape)
+
+
+def encode_tensor(a: np.ndarray, dtype: str) -> bytes:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if dtype == "F32":
+        return a.tobytes()
+    if dtype == "F16":
+        return a.astype(np.float16).tobytes()
+    if dtype == "BF16":
+        return to_bf16_bits(a).tobytes()
+    raise ValueError(dtype)
+
+
+def write_safetensors(weights: Dict[str, np.ndarray], path: str, dtype: str = "F32") -> str:
     """Plain safetensors writer (8-byte LE header length, JSON header, raw data)
-    so no third-party package is needed on the GPU box."""
+    so no third-party package is needed on the GPU box.  dtype: storage type of every tensor
+    ("F32", "F16" or "BF16": the three the native reader converts, R/safetensors.R:7-10)."""
     import json
     header = {}
     off = 0
     names = sorted(weights.keys())
+    es = 4 if dtype == "F32" else 2
     for k in names:
         a = weights[k]
         assert a.dtype == np.float32
-        n = a.size * 4
-        header[k] = {"dtype": "F32", "shape": list(a.shape), "data_offsets": [off, off + n]}
+        n = a.size * es
+        header[k] = {"dtype": dtype, "shape": list(a.shape), "data_offsets": [off, off + n]}
         off += n
     hj = json.dumps(header, separators=(",", ":")).encode()
     hj += b" " * ((8 - len(hj) % 8) % 8)
@@ -190,7 +217,7 @@ def write_safetensors(weights: Dict[str, np.ndarray], path: str) -> str:
         f.write(len(hj).to_bytes(8, "little"))
         f.write(hj)
         for k in names:
-            f.write(np.ascontiguousarray(weights[k]).tobytes())
+            f.write(encode_tensor(weights[k], dtype))
     os.replace(tmp, path)
     return path
 

@@ -26,7 +26,7 @@ from . import _lib
 
 __all__ = ["T3Model", "load_t3", "load_t3_turbo", "t3_inference", "t3_inference_cpp", "t3_inference_traced",
            "t3_inference_batch", "t3_inference_turbo", "t3_inference_turbo_batch", "Session", "T3Cond", "t3_cond",
-           "prepare_input_embeds", "split_sentences", "drop_invalid_tokens", "tts_chunked", "SPEECH_VOCAB_SIZE"]
+           "prepare_input_embeds", "inspect_checkpoint", "split_sentences", "drop_invalid_tokens", "tts_chunked", "SPEECH_VOCAB_SIZE"]
 
 _DT = {"f32": _lib.W_F32, "fp32": _lib.W_F32, "float32": _lib.W_F32, "bf16": _lib.W_BF16,
        "bfloat16": _lib.W_BF16}
@@ -37,10 +37,16 @@ class T3Model:
     the decode path: load_t3_weights R/t3.R:1061-1145 + .get_cpp_weights :884-912)."""
 
     def __init__(self, path: str, device: int = 0, dtype: str = "f32", variant: int = _lib.VARIANT_LLAMA,
-                 start_speech_token: int = 6561, stop_speech_token: int = 6562):
+                 start_speech_token: int = 6561, stop_speech_token: int = 6562, cache=None):
+        """cache: None / False = none; True = "<path>.t3mi-bf16" next to the checkpoint; a string = that file.  Only
+        bf16 storage uses it (t3mi_open_cached): the packed bf16 matrices are read back instead of converted."""
         self._lib = _lib.load()
         h = C.c_void_p()
-        _lib.check(self._lib.t3mi_open(path.encode(), variant, int(device), _DT[dtype], C.byref(h)))
+        cpath = None
+        if cache:
+            cpath = (path + ".t3mi-bf16") if cache is True else str(cache)
+        _lib.check(self._lib.t3mi_open_cached(path.encode(), variant, int(device), _DT[dtype],
+                                              cpath.encode() if cpath else None, C.byref(h)))
         self._h = h
         info = _lib.Info()
         _lib.check(self._lib.t3mi_get_info(self._h, C.byref(info)))
@@ -70,6 +76,14 @@ class T3Model:
 
 def load_t3(path: str, device: int = 0, dtype: str = "f32", **kw) -> T3Model:
     return T3Model(path, device, dtype, **kw)
+
+
+def inspect_checkpoint(path: str, variant: int = _lib.VARIANT_LLAMA) -> dict:
+    """t3mi_inspect: validate a checkpoint without a GPU (header, tensor names / shapes / dtypes) and return its
+    dimensions; raises T3miError(ERR_IO) naming the offending tensor for a truncated, mis-shaped or foreign file."""
+    info = _lib.Info()
+    _lib.check(_lib.load().t3mi_inspect(path.encode(), int(variant), C.byref(info)))
+    return {k: getattr(info, k) for k, _ in _lib.Info._fields_}
 
 
 def load_t3_turbo(path: str, device: int = 0, dtype: str = "f32", **kw) -> T3Model:

@@ -70,9 +70,17 @@ typedef struct t3mi_params {
                                     same tokens as the unsplit batch; 0 for a single call            */
 } t3mi_params;
 
+/* what t3mi_open_cached did with the packed bf16 weight file */
+#define T3MI_CACHE_NONE 0      /* no cache path given, fp32 storage, or the file could not be written       */
+#define T3MI_CACHE_WRITTEN 1   /* no file existed: weights converted from the checkpoint, cache written     */
+#define T3MI_CACHE_USED 2      /* weights read from the cache (header and checksum matched)                  */
+#define T3MI_CACHE_REPLACED 3  /* a stale / foreign / damaged file was found: converted again and rewritten  */
+
 typedef struct t3mi_info {
     int32_t variant, n_layers, d_model, n_heads, head_dim, d_ff, vocab, max_pos, wdtype, device;
     int64_t weight_bytes;        /* bytes streamed per decode step (P * b_w of SURVEY §8d)  */
+    int32_t cache_state;         /* T3MI_CACHE_*                                             */
+    int32_t has_prompt_tensors;  /* 1: text_emb / cond_enc.* present (the *_tokens entry points work) */
 } t3mi_info;
 
 /* per-kernel timing of one decode step (HIP events on the library's stream) */
@@ -96,6 +104,18 @@ int t3mi_device_count(void);
  * R/llama.R:566-607; turbo keys R/t3.R:1508-1549), upload to `device`, build RoPE tables
  * (R/llama.R:87-152).  Replaces load_t3_weights + .get_cpp_weights (R/t3.R:884-912). */
 int t3mi_open(const char* safetensors_path, int variant, int device, int wdtype, t3mi_model** out);
+/* The same with a packed bf16 weight cache (the reference loads CPU-first and converts on every start,
+ * R/tts.R:72-79): with wdtype = T3MI_W_BF16 and a non-NULL `cache_path`, the bf16 image of the streamed matrices is read
+ * from that file when its header matches the checkpoint (size, mtime in ns, variant, dims, layout version) and its
+ * checksum holds; otherwise the weights are converted from the checkpoint as t3mi_open does and the file is (re)written
+ * atomically (best effort: an unwritable path is not an error).  t3mi_get_info().cache_state tells which happened.
+ * The usual place is next to the checkpoint in the HF cache: "<safetensors_path>.t3mi-bf16". */
+int t3mi_open_cached(const char* safetensors_path, int variant, int device, int wdtype, const char* cache_path,
+                     t3mi_model** out);
+/* Validate a checkpoint WITHOUT a GPU: header, every tensor name / shape / dtype the loaders read (R/t3.R:1065-1145,
+ * R/llama.R:566-607; Turbo R/t3.R:1508-1549), and fill the dimensions.  T3MI_ERR_IO with the tensor's name for a
+ * truncated, mis-shaped or foreign file -- the same checks t3mi_open makes before its first allocation. */
+int t3mi_inspect(const char* safetensors_path, int variant, t3mi_info* info);
 int t3mi_close(t3mi_model* m);
 int t3mi_get_info(const t3mi_model* m, t3mi_info* info);
 

@@ -25,7 +25,8 @@ t3mi_default_path <- function (variant = c("llama", "turbo"))
 #' Open (once per file, device and dtype) the native model.  `path = NULL` resolves the file the R model itself was
 #' loaded from (t3mi_default_path); the handle is cached, so every t3_inference() call after the first reuses the
 #' weights already resident in HBM.
-t3mi_model <- function (path = NULL, device = 0L, dtype = c("f32", "bf16"), variant = c("llama", "turbo"))
+t3mi_model <- function (path = NULL, device = 0L, dtype = c("f32", "bf16"), variant = c("llama", "turbo"),
+                        cache = FALSE)
 {
     dtype <- match.arg(dtype)
     variant <- match.arg(variant)
@@ -34,8 +35,11 @@ t3mi_model <- function (path = NULL, device = 0L, dtype = c("f32", "bf16"), vari
         stop("t3mi_model: '", format(path), "' is not a readable safetensors file", call. = FALSE)
     key <- paste(normalizePath(path), device, dtype, variant)
     if (is.null(.t3mi[[key]])) {
+        # cache = TRUE keeps the packed bf16 weights next to the checkpoint in the HF cache ("<file>.t3mi-bf16"): the next
+        # session reads half the bytes and converts nothing; a stale or damaged cache is detected and rewritten
+        cache_path <- if (isTRUE(cache)) paste0(path, ".t3mi-bf16") else if (is.character(cache)) cache else NULL
         .t3mi[[key]] <- .Call("t3mi_r_open", path, if (variant == "turbo") 1L else 0L, as.integer(device),
-                              if (dtype == "bf16") 1L else 0L, PACKAGE = "chatterbox")
+                              if (dtype == "bf16") 1L else 0L, cache_path, PACKAGE = "chatterbox")
     }
     .t3mi[[key]]
 }

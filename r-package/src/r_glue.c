@@ -23,7 +23,7 @@ static SEXP no_backend(void) {
     Rf_error("chatterbox was built without the MI355X T3 backend (hipcc not found at configure time)");
     return R_NilValue;
 }
-SEXP t3mi_r_open(SEXP a, SEXP b, SEXP c, SEXP d) { return no_backend(); }
+SEXP t3mi_r_open(SEXP a, SEXP b, SEXP c, SEXP d, SEXP e) { return no_backend(); }
 SEXP t3mi_r_close(SEXP a) { return R_NilValue; }
 SEXP t3mi_r_generate(SEXP a, SEXP b, SEXP c, SEXP d) { return no_backend(); }
 SEXP t3mi_r_generate_batch(SEXP a, SEXP b, SEXP c, SEXP d) { return no_backend(); }
@@ -55,11 +55,13 @@ static t3mi_model* get_model(SEXP ptr) {
     return m;
 }
 
-/* .Call("t3mi_r_open", path, variant, device, dtype) -> external pointer */
-SEXP t3mi_r_open(SEXP path, SEXP variant, SEXP device, SEXP dtype) {
+/* .Call("t3mi_r_open", path, variant, device, dtype, cache_path or NULL) -> external pointer */
+SEXP t3mi_r_open(SEXP path, SEXP variant, SEXP device, SEXP dtype, SEXP cache) {
     t3mi_model* m = NULL;
-    int rc = t3mi_open(CHAR(STRING_ELT(path, 0)), Rf_asInteger(variant), Rf_asInteger(device),
-                       Rf_asInteger(dtype), &m);
+    if (TYPEOF(path) != STRSXP || Rf_length(path) != 1) Rf_error("t3mi_open: path must be one string");
+    const char* cp = (TYPEOF(cache) == STRSXP && Rf_length(cache) == 1) ? CHAR(STRING_ELT(cache, 0)) : NULL;
+    int rc = t3mi_open_cached(CHAR(STRING_ELT(path, 0)), Rf_asInteger(variant), Rf_asInteger(device),
+                              Rf_asInteger(dtype), cp, &m);
     if (rc != T3MI_OK) Rf_error("t3mi_open: %s", t3mi_last_error());
     SEXP ptr = PROTECT(R_MakeExternalPtr(m, R_NilValue, R_NilValue));
     R_RegisterCFinalizerEx(ptr, model_finalizer, TRUE);
@@ -274,7 +276,7 @@ SEXP t3mi_r_generate_tokens(SEXP model, SEXP conds, SEXP texts, SEXP cfg) {
 #endif /* HAVE_T3MI */
 
 static const R_CallMethodDef call_methods[] = {
-    {"t3mi_r_open", (DL_FUNC)&t3mi_r_open, 4},
+    {"t3mi_r_open", (DL_FUNC)&t3mi_r_open, 5},
     {"t3mi_r_close", (DL_FUNC)&t3mi_r_close, 1},
     {"t3mi_r_generate", (DL_FUNC)&t3mi_r_generate, 4},
     {"t3mi_r_generate_batch", (DL_FUNC)&t3mi_r_generate_batch, 4},
