@@ -34,6 +34,8 @@ class Params(C.Structure):
         ("mask_stop", C.c_int32),
         ("seed", C.c_uint64),
         ("first_utterance_id", C.c_int64),
+        ("drop_invalid_from", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 

@@ -684,6 +684,36 @@ __global__ __launch_bounds__(256) void prefill_embed_kernel(EmbedArgs a) {
     for (int i = threadIdx.x; i < a.d; i += blockDim.x) a.x[(size_t)r * a.d + i] = src[i];
 }
 
+// ---- drop_invalid_tokens (R/s3tokenizer.R:678-687): stable compaction of the ids below `limit` ---------------------
+// One 256-thread block per utterance walks the stream in chunks of 256: keep flags -> wave ballots -> exclusive offsets
+// (popcount below the lane + the earlier waves' counts through LDS) -> scatter.  Integer work, bit-exact by construction.
+__global__ __launch_bounds__(256) void drop_invalid_kernel(const int* __restrict__ tokens, const int* __restrict__ n_tokens, int cap,
+                                                           int limit, int* __restrict__ kept, int* __restrict__ n_kept) {
+    __shared__ int wave_cnt[4];
+    __shared__ int base;
+    const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(n_tokens[u], cap);
+    const int* src = tokens + (size_t)u * cap;
+    int* dst = kept + (size_t)u * cap;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const int tok = i < n ? src[i] : limit;
+        const bool keep = i < n && tok >= 0 && tok < limit;
+        const unsigned long long mask = __ballot(keep);
+        if (lane == 0) wave_cnt[wave] = __popcll(mask);
+        __syncthreads();
+        int off = base + __popcll(mask & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (keep) dst[off] = tok;
+        __syncthreads();
+        if (tid == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) n_kept[u] = base;
+}
+
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1256,6 +1286,13 @@ hipError_t init_device() {
     // the sampler carves > 64 KiB of dynamic LDS; call once per device before any launch / capture
     return hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_drop_invalid(const int* tokens, const int* n_tokens, int cap, int limit, int* kept, int* n_kept, int n_utt,
+                               hipStream_t s) {
+    if (!tokens || !n_tokens || !kept || !n_kept || cap <= 0 || n_utt <= 0 || limit <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(drop_invalid_kernel, dim3(n_utt), dim3(256), 0, s, tokens, n_tokens, cap, limit, kept, n_kept);
+    return hipGetLastError();
 }
 
 hipError_t launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {

@@ -184,6 +184,10 @@ hipError_t launch_scale_row(const float* w, float sc, float* out, int d, hipStre
 // unmasked multi-head attention: q [Mq, H*Dh], k / v [Mk, H*Dh] -> out [Mq, H*Dh], all fp32
 hipError_t launch_mha_rows(const float* q, const float* k, const float* v, float* out, int Mq, int Mk, int H, int Dh,
                            hipStream_t s);
+// drop_invalid_tokens (R/s3tokenizer.R:678-687) on device: kept[u][0 .. n_kept[u]) = the ids of tokens[u][0 .. min(n_tokens[u], cap))
+// that are < limit, in order.  One block per utterance.
+hipError_t launch_drop_invalid(const int* tokens, const int* n_tokens, int cap, int limit, int* kept, int* n_kept, int n_utt,
+                               hipStream_t s);
 // fp32 -> bf16 (round to nearest even) on device, n elements
 hipError_t launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 

@@ -1150,6 +1150,7 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     }
     if (!(p->repetition_penalty > 0.f)) return fail(T3MI_ERR_ARG, "repetition_penalty must be > 0");
     if (p->stop_token < 0 || p->stop_token >= m->V) return fail(T3MI_ERR_ARG, "stop_token outside the vocabulary");
+    if (p->drop_invalid_from < 0) return fail(T3MI_ERR_ARG, "drop_invalid_from must be >= 0");
     HIPCHK(hipSetDevice(m->device));
     if (m->sess) t3mi_session_end(m);
 
@@ -1592,7 +1593,25 @@ static int run_generate(t3mi_model* m, int n_utt, int32_t* out, int32_t cap, int
         for (int u = 0; u < n_utt; ++u) all_done = all_done && done[u] != 0;
     }
     int warn = T3MI_OK;
-    if (!rc) {
+    if (!rc && s->prm.drop_invalid_from > 0) {
+        // generate()'s next step on the T3 output (R/tts.R:366): drop_invalid_tokens, here on the device before the copy
+        DevBuf kept, nk;
+        hipError_t e = kept.alloc((size_t)n_utt * s->cap * 4);
+        if (e == hipSuccess) e = nk.alloc((size_t)n_utt * 4);
+        if (e == hipSuccess)
+            e = t3k::launch_drop_invalid(s->tokens.as<int>(), s->n_tokens.as<int>(), s->cap, s->prm.drop_invalid_from, kept.as<int>(),
+                                         nk.as<int>(), n_utt, m->stream);
+        std::vector<int32_t> nkh(n_utt);
+        if (e == hipSuccess) e = hipMemcpyAsync(nkh.data(), nk.p, (size_t)n_utt * 4, hipMemcpyDeviceToHost, m->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+        for (int u = 0; u < n_utt && e == hipSuccess; ++u) {
+            n_out[u] = std::min(nkh[u], cap);
+            if (n_out[u] > 0)
+                e = hipMemcpy(out + (size_t)u * cap, kept.as<int>() + (size_t)u * s->cap, (size_t)n_out[u] * 4, hipMemcpyDeviceToHost);
+            if (done[u] == 3) warn = T3MI_WARN_CACHE_FULL;
+        }
+        if (e != hipSuccess) rc = fail(T3MI_ERR_HIP, std::string("drop_invalid_tokens: ") + hipGetErrorString(e));
+    } else if (!rc) {
         for (int u = 0; u < n_utt && !rc; ++u) {
             rc = t3mi_session_tokens(m, u, out + (size_t)u * cap, cap, &n_out[u]);
             if (done[u] == 3) warn = T3MI_WARN_CACHE_FULL;

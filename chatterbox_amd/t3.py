@@ -92,7 +92,7 @@ def load_t3_turbo(path: str, device: int = 0, dtype: str = "f32", **kw) -> T3Mod
 
 
 def _params(model: T3Model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
-            sampler, max_cache_len=0, seed=0, mask_stop=False, top_k=0, first_utterance_id=0) -> _lib.Params:
+            sampler, max_cache_len=0, seed=0, mask_stop=False, top_k=0, first_utterance_id=0, drop_invalid=None) -> _lib.Params:
     p = _lib.Params()
     model._lib.t3mi_default_params(C.byref(p))
     p.max_new_tokens = int(max_new_tokens)
@@ -109,6 +109,8 @@ def _params(model: T3Model, max_new_tokens, temperature, cfg_weight, top_p, min_
     p.mask_stop = 1 if mask_stop else 0
     p.seed = int(seed)
     p.first_utterance_id = int(first_utterance_id)
+    # drop_invalid: True = SPEECH_VOCAB_SIZE (6561, R/s3tokenizer.R:7), an int = that limit, None / False = raw stream
+    p.drop_invalid_from = 0 if not drop_invalid else (SPEECH_VOCAB_SIZE if drop_invalid is True else int(drop_invalid))
     return p
 
 
@@ -274,13 +276,13 @@ def t3_inference_batch(model: T3Model, embeds_list: Sequence, text_tokens_list: 
                        max_new_tokens: int = 1000,
                        temperature: float = 0.8, cfg_weight: float = 0.5, top_p: float = 0.95,
                        min_p: float = 0.05, repetition_penalty: float = 1.2, seed: int = 0,
-                       mask_stop: bool = False, first_utterance_id: int = 0) -> List[np.ndarray]:
+                       mask_stop: bool = False, first_utterance_id: int = 0, drop_invalid=None) -> List[np.ndarray]:
     """Independent utterances decoded together (the batch axis tts_chunked leaves serial,
     R/tts.R:462-474).  Same per-utterance semantics as t3_inference.  Utterance u of the call draws from the
     RNG stream (seed, first_utterance_id + u): a batch cut into several calls (or sharded over GPUs,
     chatterbox_amd.shard) samples the same tokens as the one-call batch."""
     p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
-                _lib.SAMPLER_R, 0, seed, mask_stop, first_utterance_id=first_utterance_id)
+                _lib.SAMPLER_R, 0, seed, mask_stop, first_utterance_id=first_utterance_id, drop_invalid=drop_invalid)
     if text_tokens_list is not None:        # embeds_list holds T3Cond objects, one per utterance
         return _generate_tokens(model, list(embeds_list), list(text_tokens_list), p, int(max_new_tokens))
     es = [_as_embeds(model, e, cfg_weight) for e in embeds_list]
@@ -300,12 +302,12 @@ def t3_inference_turbo_batch(model: T3Model, embeds_list: Sequence, text_tokens_
                              max_new_tokens: int = 1000,
                              temperature: float = 0.8, top_k: int = 1000, top_p: float = 0.95,
                              repetition_penalty: float = 1.2, seed: int = 0, mask_stop: bool = False,
-                             keep_stop: bool = False, first_utterance_id: int = 0) -> List[np.ndarray]:
+                             keep_stop: bool = False, first_utterance_id: int = 0, drop_invalid=None) -> List[np.ndarray]:
     """Independent Turbo utterances decoded together; per-utterance semantics of t3_inference_turbo."""
     if model.variant != _lib.VARIANT_TURBO:
         raise ValueError("t3_inference_turbo needs a model opened with load_t3_turbo")
     p = _params(model, max_new_tokens, temperature, 0.0, top_p, 0.0, repetition_penalty,
-                _lib.SAMPLER_TURBO, 0, seed, mask_stop, top_k, first_utterance_id=first_utterance_id)
+                _lib.SAMPLER_TURBO, 0, seed, mask_stop, top_k, first_utterance_id=first_utterance_id, drop_invalid=drop_invalid)
     cap = int(max_new_tokens) + 1            # first token from the prefill + max_new_tokens more (R/t3.R:1614-1658)
     if text_tokens_list is not None:         # embeds_list holds T3Cond objects
         toks = _generate_tokens(model, list(embeds_list), list(text_tokens_list), p, cap)
@@ -382,12 +384,12 @@ def tts_chunked(model: T3Model, text: str, cond: T3Cond, tokenize, chunk_size: i
     turbo = model.variant == _lib.VARIANT_TURBO
     toks = [np.asarray(tokenize(s), dtype=np.int32).reshape(-1) for s in sentences]
     fn = t3_inference_turbo_batch if turbo else t3_inference_batch
+    # drop_invalid_tokens runs on the device at the end of the generate call (t3mi_params.drop_invalid_from)
+    di = (drop_invalid if drop_invalid is not True else SPEECH_VOCAB_SIZE) if drop_invalid else None
     if batched:
-        out = fn(model, [cond] * len(sentences), toks, **kw)
+        out = fn(model, [cond] * len(sentences), toks, drop_invalid=di, **kw)
     else:
-        out = [fn(model, [cond], [t], first_utterance_id=i, **kw)[0] for i, t in enumerate(toks)]
-    if drop_invalid:
-        out = [drop_invalid_tokens(t) for t in out]
+        out = [fn(model, [cond], [t], first_utterance_id=i, drop_invalid=di, **kw)[0] for i, t in enumerate(toks)]
     return {"sentences": sentences, "speech_tokens": out}
 
 

@@ -68,6 +68,11 @@ typedef struct t3mi_params {
     int64_t first_utterance_id;  /* global index of utterance 0 of this call: utterance u draws from the RNG stream
                                     (seed, first_utterance_id + u), so a batch split over calls / ranks samples the
                                     same tokens as the unsplit batch; 0 for a single call            */
+    int32_t drop_invalid_from;   /* > 0: the generate entry points return the stream with every id >= this value removed,
+                                    order kept: drop_invalid_tokens (R/s3tokenizer.R:678-687, SPEECH_VOCAB_SIZE 6561), which
+                                    generate() applies to the T3 output before S3Gen (R/tts.R:366); filtered on the
+                                    device.  0 = return the raw stream (t3_inference's own contract, Q14)               */
+    int32_t reserved_;
 } t3mi_params;
 
 /* what t3mi_open_cached did with the packed bf16 weight file */

@@ -419,6 +419,16 @@ def t3_inference(model: LlamaOracle, embeds: np.ndarray, p: SampleParams, utt: i
     return tr
 
 
+SPEECH_VOCAB_SIZE = 6561    # R/s3tokenizer.R:7
+
+
+def drop_invalid_tokens(tokens: Sequence[int], speech_vocab_size: int = SPEECH_VOCAB_SIZE) -> np.ndarray:
+    """R/s3tokenizer.R:678-687: `tokens[tokens < SPEECH_VOCAB_SIZE]` -- the ids of the start / stop / padding range are
+    removed, order kept.  generate() applies it to the T3 output before S3Gen (R/tts.R:366)."""
+    t = np.asarray(list(tokens), dtype=np.int64)
+    return t[t < speech_vocab_size]
+
+
 # --------------------------------------------------------------------------
 # Turbo T3: GPT-2 medium backbone (R/t3.R:1190-1410) + sampler (R/t3.R:1688-1742)
 # --------------------------------------------------------------------------

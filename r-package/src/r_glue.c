@@ -91,6 +91,7 @@ static void fill_params(SEXP cfg, t3mi_params* p) {
     p->max_cache_len = (int32_t)cfg_real(cfg, "max_cache_len", 0, 0);
     p->seed = (uint64_t)cfg_real(cfg, "seed", 0, 0);
     p->first_utterance_id = (int64_t)cfg_real(cfg, "first_utterance_id", 0, 0);
+    p->drop_invalid_from = (int32_t)cfg_real(cfg, "drop_invalid_from", 0, 0);   /* drop_invalid_tokens on device (R/tts.R:366) */
 }
 
 /* R arrays are column-major doubles: embeds[r, t, k] sits at r + rows*(t + s0*k).  Returns NULL for a wrong shape or

@@ -325,3 +325,28 @@ def test_tts_chunked_batch_equals_serial():
         assert all(list(cb.drop_invalid_tokens(x)) == list(y) for x, y in zip(one, got["speech_tokens"]))
     finally:
         model.close()
+
+
+def test_drop_invalid_tokens_on_device():
+    """f4, first piece (R/s3tokenizer.R:678-687, applied by generate() at R/tts.R:366): with drop_invalid_from set the
+    generate entry points return the stream filtered ON THE DEVICE; bit-exact against the oracle's filter of the raw
+    stream of the same call, for a ragged batch, streams longer than one 256-token chunk, a limit that drops from the
+    middle of the stream, and a limit that drops everything."""
+    dims, path = _peaked()
+    model = cb.load_t3(path, device=0, start_speech_token=dims.start_speech_token, stop_speech_token=dims.stop_speech_token)
+    try:
+        embs = [synth.synth_embeds(2, 7 + 3 * u, dims.hidden_size, 810 + u) for u in range(5)]
+        kw = dict(max_new_tokens=300, seed=3, top_p=0.999, min_p=0.0, temperature=1.5)
+        raw = cb.t3_inference_batch(model, embs, **kw)
+        assert max(len(t) for t in raw) > 256
+        for limit in (dims.start_speech_token, 500, 37, 1):
+            got = cb.t3_inference_batch(model, embs, drop_invalid=limit, **kw)
+            for u in range(5):
+                want = O.drop_invalid_tokens(raw[u], limit)
+                assert list(got[u]) == list(want), f"limit {limit} utterance {u}"
+        assert any(len(O.drop_invalid_tokens(raw[u], 500)) not in (0, len(raw[u])) for u in range(5))
+        # the stop token belongs to the dropped range (R/tts.R:366 removes it together with the other specials)
+        stop = cb.t3_inference_batch(model, embs[:2], max_new_tokens=300, seed=3, drop_invalid=dims.start_speech_token)
+        assert all(dims.stop_speech_token not in t and (len(t) == 0 or t.max() < dims.start_speech_token) for t in stop)
+    finally:
+        model.close()

@@ -99,3 +99,15 @@ def test_counter_uniform_range_and_determinism():
     us = [O.counter_uniform(7, u, s) for u in range(4) for s in range(64)]
     assert all(0.0 <= x < 1.0 for x in us) and len(set(us)) > 250
     assert O.counter_uniform(7, 1, 2) == O.counter_uniform(7, 1, 2)
+
+
+def test_kat6_drop_invalid_tokens_on_the_reference_streams(golden_dir):
+    """KAT-6 (R/s3tokenizer.R:678-687): both token streams the reference ships end in the stop token 6562 and hold
+    nothing else from the special range, so drop_invalid_tokens removes exactly the last id."""
+    g = np.load(os.path.join(golden_dir, "ref_tokens.npz"))
+    for k in ("speech_tokens", "python_generated"):
+        t = g[k].astype(np.int64)
+        kept = O.drop_invalid_tokens(t)
+        assert t[-1] == 6562 and list(kept) == list(t[:-1]) and kept.max() < O.SPEECH_VOCAB_SIZE
+    assert list(O.drop_invalid_tokens([6561, 5, 6560, 8193, 0, 6562, 7])) == [5, 6560, 0, 7]
+    assert O.drop_invalid_tokens([]).size == 0
