@@ -160,6 +160,7 @@ SEXP t3mi_r_generate_batch(SEXP model, SEXP embeds_list, SEXP dims, SEXP cfg) {
         e[u] = to_row_major(VECTOR_ELT(embeds_list, u), rows, s0[u], d);
         if (!e[u]) rc = T3MI_ERR_ARG;   /* wrong shape / out of memory: everything is freed below before Rf_error */
     }
+    const int bad_args = rc != T3MI_OK;   /* refused here (shapes, memory), as opposed to refused by the library */
     if (rc == T3MI_OK)
         rc = t3mi_generate_batch(m, n_utt, rows, (const float* const*)e, s0, &p, out, cap, n_out);
     if (e) for (int u = 0; u < n_utt; u++) free(e[u]);
@@ -168,7 +169,8 @@ SEXP t3mi_r_generate_batch(SEXP model, SEXP embeds_list, SEXP dims, SEXP cfg) {
     if (rc < 0) {
         free(out);
         free(n_out);
-        Rf_error("t3mi_generate_batch: %s", rc == T3MI_ERR_ARG ? "bad arguments" : t3mi_last_error());
+        Rf_error("t3mi_generate_batch: %s", bad_args ? "bad arguments: every element must be a numeric [rows, S0, d] array "
+                 "matching its row of dims" : t3mi_last_error());
     }
     SEXP res = PROTECT(Rf_allocVector(VECSXP, n_utt));
     for (int u = 0; u < n_utt; u++) {

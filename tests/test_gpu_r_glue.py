@@ -1,0 +1,144 @@
+"""The R glue (r-package/src/r_glue.c) executed: there is no R in the build image, so the glue is compiled against a
+minimal test double of the R C API (tests/r_mock: vectors with names, external pointers with finalizers, Rf_error as a
+non-local exit) and driven the way `.Call` drives it -- named config list as R/t3.R:1022-1034 builds it, t3_cond as
+plain vectors, a column-major [rows, S0, d] array -- against the same library the ctypes path uses.  Results must be
+identical to the ctypes path; every error path must free its C state and leave the handle usable."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import chatterbox_amd as cb
+from chatterbox_amd import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "r_mock", "librglue_mock.so")
+
+
+class MockCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("max_tokens", "sampler", "top_k", "max_cache_len", "start_token", "stop_token", "omit_required")] + \
+               [(n, C.c_double) for n in ("temperature", "cfg_weight", "top_p", "min_p", "rep_penalty", "seed")]
+
+
+@pytest.fixture(scope="module")
+def glue():
+    if not os.path.exists(LIB):
+        pytest.fail(f"{LIB} is not built (make -C tests/r_mock, or __graft_entry__.build())")
+    lib = C.CDLL(LIB)
+    lib.mock_last_error.restype = C.c_char_p
+    lib.mock_last_warning.restype = C.c_char_p
+    dims = synth.TINY
+    path = synth.ensure_checkpoint(dims, 1234)
+    assert lib.mock_open(path.encode(), 0, 0, 0, None) == 0, lib.mock_last_error()
+    model = cb.load_t3(path, device=0, start_speech_token=dims.start_speech_token, stop_speech_token=dims.stop_speech_token)
+    yield lib, dims, model
+    model.close()
+    assert lib.mock_close() == 0                      # the finalizer closed the handle and cleared the pointer
+
+
+def _cfg(dims, **kw):
+    c = MockCfg(max_tokens=12, sampler=0, top_k=0, max_cache_len=0, start_token=dims.start_speech_token,
+                stop_token=dims.stop_speech_token, omit_required=0, temperature=0.8, cfg_weight=0.5, top_p=0.0, min_p=0.05,
+                rep_penalty=1.2, seed=0.0)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _tokens_call(lib, dims, conds, texts, cfg, wrong_types=0):
+    n = len(conds)
+    spk = np.ascontiguousarray(np.stack([c[0] for c in conds]).astype(np.float64))
+    ct = [np.ascontiguousarray(c[1], dtype=np.int32) for c in conds]
+    tx = [np.ascontiguousarray(t, dtype=np.int32) for t in texts]
+    IP = C.POINTER(C.c_int32)
+    ctp = (IP * n)(*[a.ctypes.data_as(IP) for a in ct])
+    txp = (IP * n)(*[a.ctypes.data_as(IP) for a in tx])
+    nct = (C.c_int32 * n)(*[a.size for a in ct])
+    ntx = (C.c_int32 * n)(*[a.size for a in tx])
+    emo = (C.c_double * n)(*[float("nan") if c[2] is None else c[2] for c in conds])
+    cap = cfg.max_tokens + 1
+    out = np.zeros((n, cap), np.int32)
+    n_out = (C.c_int32 * n)()
+    rc = lib.mock_generate_tokens(n, spk.ctypes.data_as(C.POINTER(C.c_double)), spk.shape[1], ctp, nct, emo, txp, ntx, C.byref(cfg),
+                                  wrong_types, out.ctypes.data_as(IP), cap, n_out)
+    return rc, [list(out[u, :n_out[u]]) for u in range(n)]
+
+
+def test_generate_tokens_through_the_glue_equals_the_ctypes_path(glue):
+    lib, dims, model = glue
+    rng = np.random.default_rng(5)
+    conds = [((rng.standard_normal(dims.speaker_embed) * 0.1).astype(np.float32), rng.integers(0, dims.start_speech_token, 20 + 7 * u),
+              0.5 if u != 1 else None) for u in range(3)]
+    texts = [rng.integers(1, 250, 4 + 3 * u) for u in range(3)]
+    rc, got = _tokens_call(lib, dims, conds, texts, _cfg(dims))
+    assert rc == 0, lib.mock_last_error()
+    want = cb.t3_inference_batch(model, [cb.t3_cond(s, t, emotion_adv=e) for s, t, e in conds], texts, max_new_tokens=12, top_p=0.0)
+    assert got == [list(map(int, w)) for w in want]
+    assert lib.mock_protect_balance() == 0
+    # sampled, cpp rule, seed and cache cap read by name from the list
+    cfg = _cfg(dims, top_p=0.9, sampler=1, max_cache_len=64, seed=7.0, max_tokens=30)
+    rc, got = _tokens_call(lib, dims, conds[:1], texts[:1], cfg)
+    assert rc == 0, lib.mock_last_error()
+    want = cb.t3_inference_cpp(model, cb.t3_cond(*conds[0][:2], emotion_adv=conds[0][2]), texts[0], max_new_tokens=30, top_p=0.9,
+                               max_cache_len=64, seed=7)
+    stop = dims.stop_speech_token
+    g = got[0][:got[0].index(stop)] if stop in got[0] else got[0]
+    assert g == list(map(int, want))
+
+
+def test_generate_from_a_column_major_array(glue):
+    lib, dims, model = glue
+    emb = synth.synth_embeds(2, 9, dims.hidden_size, 31)
+    cfg = _cfg(dims)
+    out = np.zeros(cfg.max_tokens + 1, np.int32)
+    n = C.c_int32(0)
+    rc = lib.mock_generate(emb.ctypes.data_as(C.POINTER(C.c_float)), 2, 9, dims.hidden_size, C.byref(cfg), 0,
+                           out.ctypes.data_as(C.POINTER(C.c_int32)), out.size, C.byref(n))
+    assert rc == 0, lib.mock_last_error()
+    want = cb.t3_inference(model, emb, max_new_tokens=12, top_p=0.0)
+    assert list(out[:n.value]) == list(map(int, want))
+    # dims that do not match the array: refused with a message, C buffers freed, the handle still works
+    rc = lib.mock_generate(emb.ctypes.data_as(C.POINTER(C.c_float)), 2, 9, dims.hidden_size, C.byref(cfg), 1,
+                           out.ctypes.data_as(C.POINTER(C.c_int32)), out.size, C.byref(n))
+    assert rc == -1 and b"numeric [rows, S0, d] array" in lib.mock_last_error()
+    rc = lib.mock_generate(emb.ctypes.data_as(C.POINTER(C.c_float)), 2, 9, dims.hidden_size, C.byref(cfg), 0,
+                           out.ctypes.data_as(C.POINTER(C.c_int32)), out.size, C.byref(n))
+    assert rc == 0 and list(out[:n.value]) == list(map(int, want))
+
+
+def test_generate_batch_ragged_and_error_paths(glue):
+    lib, dims, model = glue
+    embs = [synth.synth_embeds(2, 6 + 2 * u, dims.hidden_size, 60 + u) for u in range(3)]
+    FP, IP = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    ptrs = (FP * 3)(*[e.ctypes.data_as(FP) for e in embs])
+    s0 = (C.c_int32 * 3)(*[e.shape[1] for e in embs])
+    cfg = _cfg(dims)
+    cap = cfg.max_tokens + 1
+    out = np.zeros((3, cap), np.int32)
+    n_out = (C.c_int32 * 3)()
+    rc = lib.mock_generate_batch(3, ptrs, 2, s0, dims.hidden_size, C.byref(cfg), -1, out.ctypes.data_as(IP), cap, n_out)
+    assert rc == 0, lib.mock_last_error()
+    want = cb.t3_inference_batch(model, embs, max_new_tokens=12, top_p=0.0)
+    assert [list(out[u, :n_out[u]]) for u in range(3)] == [list(map(int, w)) for w in want]
+    # a mis-shaped array in the MIDDLE of the batch (after earlier conversions were malloc'ed) must not leak or crash
+    for bad in (0, 1, 2):
+        rc = lib.mock_generate_batch(3, ptrs, 2, s0, dims.hidden_size, C.byref(cfg), bad, out.ctypes.data_as(IP), cap, n_out)
+        assert rc == -1 and b"bad arguments" in lib.mock_last_error()
+    # a config list without its required entries: the reference's own message (src/t3_decode.cpp:50)
+    rc = lib.mock_generate_batch(3, ptrs, 2, s0, dims.hidden_size, C.byref(_cfg(dims, omit_required=1)), -1, out.ctypes.data_as(IP), cap, n_out)
+    assert rc == -1 and b"Missing config parameter: rep_penalty" in lib.mock_last_error()
+    # library-side refusal (cfg_weight > 0 with ... a negative temperature) comes back as the library's text
+    rc = lib.mock_generate_batch(3, ptrs, 2, s0, dims.hidden_size, C.byref(_cfg(dims, temperature=-1.0)), -1, out.ctypes.data_as(IP), cap, n_out)
+    assert rc == -1 and b"temperature" in lib.mock_last_error()
+    rc = lib.mock_generate_batch(3, ptrs, 2, s0, dims.hidden_size, C.byref(cfg), -1, out.ctypes.data_as(IP), cap, n_out)
+    assert rc == 0 and lib.mock_protect_balance() == 0
+
+
+def test_text_ids_of_the_wrong_r_type_are_refused(glue):
+    lib, dims, model = glue
+    rng = np.random.default_rng(9)
+    conds = [((rng.standard_normal(dims.speaker_embed) * 0.1).astype(np.float32), rng.integers(0, dims.start_speech_token, 10), 0.5)]
+    rc, _ = _tokens_call(lib, dims, conds, [rng.integers(1, 250, 5)], _cfg(dims), wrong_types=1)
+    assert rc == -1 and b"text_tokens integer" in lib.mock_last_error()
