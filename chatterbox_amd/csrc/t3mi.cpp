@@ -724,9 +724,13 @@ int run_layers(t3mi_model* m, Session* s, StepTimer* tm) {
             const int rem = s->rows - r0, rg = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
             t3k::GemvArgs a;
             a.W = lw.wo; a.N = d; a.K = d; a.rows = rg;
+#ifdef T3K_DIAG_PLAIN_OPROJ   // measurement aid, separate diagnostic library only (make diag): o_proj as a plain GEMV
+            a.x = s->qbuf.as<float>() + (size_t)r0 * d;
+#else
             a.pm = s->pm.as<float>() + (size_t)r0 * H * s->n_split;
             a.pl = s->pl.as<float>() + (size_t)r0 * H * s->n_split;
             a.pacc = s->pacc.as<float>() + (size_t)r0 * H * s->n_split * 64;
+#endif
             a.n_split_max = s->n_split; a.keys_per_split = s->kps;
             a.rowpos = s->rowpos.as<int>() + r0;
             a.y = s->x.as<float>() + (size_t)r0 * d; a.resid = a.y; a.ldy = d;
