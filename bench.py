@@ -280,6 +280,8 @@ def sharded_workload(rk: Ranks, cb, model, total: int, s0: int, dtype: str, K: i
             "hip_event_ms_per_step": round(ev_ms / K, 4), "prefill_ms": round(prefill_ms, 1),
             "bytes_per_step_per_gpu": int(bstep), "GBps_per_gpu": round(bstep / (step_us * 1e-6) / 1e9, 1),
             "frac": round(bstep / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            # bit-reproducible run to run for one rank count; across rank counts the rows per GPU change the GEMM tiling,
+            # and with it the bf16 rounding of a few activations, so near-tied greedy picks (and this sum) may differ
             "token_checksum": int(sum(int(t.sum()) for t in toks) % (1 << 31))}
 
 
@@ -481,11 +483,19 @@ def main():
     world, rank, local_rank, spawn = resolve_world(args.gpus)
     if spawn:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    # stdout carries exactly ONE JSON line: whatever libraries print there while the run lasts (gloo's "[Gloo] Rank 0 is
+    # connected ..." goes to stdout) is sent to stderr, and the line is written to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rk, out = run(args, world, rank, local_rank)
+    rk.close()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
     if rank == 0 and out is not None:
         print(json.dumps(out))
         sys.stdout.flush()
-    rk.close()
 
 
 if __name__ == "__main__":
