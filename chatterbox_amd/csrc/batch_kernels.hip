@@ -26,6 +26,7 @@ constexpr int kHeadDim = 64;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // 16 bytes in flight (a native vector: arrays of HIP's uint4 struct are copied with memcpy and can stay in scratch memory)
 
 __device__ __forceinline__ uint16_t f2bf(float f) {
     const uint32_t u = __float_as_uint(f);
@@ -1041,6 +1042,159 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a, int tiles32,
     if (dbg) dbg[3] = wall_clock64();
 }
 
+// ---- bf16 many-row GEMM, third generation: activation-stationary, for <= 128 rows --------------------------------
+// gemm_rows_kernel stages activations AND weights through LDS once per 128-k step, with a block barrier per step:
+// at 64-128 rows it is bound by LDS traffic and by the barriers, not by HBM.  Here the 64 activation rows of a block
+// (64 x KB bf16, KB = 1024: 128 KB) go to LDS ONCE and stay; the weights never touch LDS: they are read from a
+// FRAGMENT-MAJOR copy of the matrix (fragment_weights_kernel: the 64 x 16 B of one MFMA B operand -- 16 features x 32 k
+// -- are contiguous, so a wave's load of one fragment is one 1 KB run), straight into the registers the MFMA takes.
+// A block owns NSUB sub-tiles of 16 features (NSUB / 2 partner tiles of 32, as tile32_feature lays them out) and its
+// 8 waves are NSUB sub-tiles x KW = 8 / NSUB slices of the block's K range: wave (sub, kw) holds 4 accumulator tiles
+// (64 rows x 16 features), issues all JW = KB / 32 / KW weight fragments of its slice at kernel start (they arrive
+// while the activations are staged), and after the one barrier runs JW x 4 MFMAs on fragments read from LDS.  The
+// slices' accumulators meet in LDS (fixed order kw = 0, 1, ..: deterministic), where the partner sub-tiles also meet
+// for the fused epilogues.  K > KB (down_proj) is split over blockIdx.z into the fp32 partial slabs the row norms fold.
+template <int EPI>
+__global__ __launch_bounds__(64) void fragment_weights_kernel(const uint16_t* __restrict__ W, uint16_t* __restrict__ out, int N, int K) {
+    const int ksteps = K >> 5;
+    const int q = blockIdx.x / ksteps, j = blockIdx.x % ksteps;   // sub-tile, 32-k step
+    const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+    const int f = tile32_feature<EPI>(q >> 1, ((q & 1) << 4) + n, N);
+    uint4 v{0u, 0u, 0u, 0u};
+    if (f < N) v = *reinterpret_cast<const uint4*>(W + (size_t)f * K + 32 * j + 8 * g);
+    reinterpret_cast<uint4*>(out)[(size_t)blockIdx.x * 64 + lane] = v;
+}
+
+constexpr int kAsRedStride = 20;   // floats per (row) of the reduction buffer: the 4 lane groups of a store hit 4 x 16 distinct banks
+
+template <int EPI, int NSUB, int KB, int MC>
+__global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
+    using T = uint16_t;
+    constexpr int KW = 8 / NSUB;             // K slices: waves per sub-tile
+    constexpr int NPH = KB / 256;            // staging phases of 256 k (512 B of every row)
+    constexpr int JQ = 8 / KW;               // MFMA k-steps per wave and phase (a phase is 8 steps of 32 k)
+    constexpr int JW = NPH * JQ;             // MFMA k-steps per wave
+    constexpr int NT = MC / 16;              // accumulator tiles per wave = staging pieces per thread and phase
+    constexpr int LDA = KB + 8;              // LDS row stride in elements (+16 B: 16-row fragment reads fall in distinct banks)
+    constexpr int RS = kAsRedStride;
+    extern __shared__ __attribute__((aligned(16))) unsigned char as_raw[];
+    T* lds = reinterpret_cast<T*>(as_raw);   // [MC][LDA], later float red[KW][NSUB][MC][RS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = lane & 15, g = lane >> 4;
+    const int sub = wave % NSUB, kw = wave / NSUB;
+    const int m0 = blockIdx.y * MC, kz = blockIdx.z;
+    const int K = a.K;
+    unsigned long long* dbg = a.dbg != nullptr && tid == 0
+                                  ? a.dbg + 4 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
+    if (dbg) dbg[0] = wall_clock64();
+    // Every global load of the kernel is issued here, activations first: they come from L2 and are consumed first, and
+    // loads complete in order.  Phase q of the activation rows = k 256 q .. 256 q + 255 of the block's range: 32 pieces of
+    // 16 B per row, piece tid + 512 i -> row (tid + 512 i) / 32 (32 consecutive threads fetch one 512-byte run).
+    u32x4 va[NPH * NT];
+    {
+        const T* Ap = static_cast<const T*>(a.A) + (size_t)kz * KB + (tid & 31) * 8;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            int row = m0 + ((tid + 512 * i) >> 5);
+            row = row < a.M ? row : a.M - 1;
+            const T* rp = Ap + (size_t)row * K;
+#pragma unroll
+            for (int q = 0; q < NPH; ++q) va[q * NT + i] = *reinterpret_cast<const u32x4*>(rp + q * 256);
+        }
+    }
+    // this wave's weight fragments: sub-tile qs, k-steps 8 q + JQ kw + jj of the block's range (1 KB each, contiguous per wave)
+    int qs = blockIdx.x * NSUB + sub;
+    qs = qs < 2 * tiles32 ? qs : 2 * tiles32 - 1;
+    const u32x4* wp = reinterpret_cast<const u32x4*>(a.Wf) + ((size_t)qs * (K >> 5) + (size_t)kz * (KB / 32) + kw * JQ) * 64 + lane;
+    u32x4 wf[JW];
+#pragma unroll
+    for (int q = 0; q < NPH; ++q)
+#pragma unroll
+        for (int jj = 0; jj < JQ; ++jj) wf[q * JQ + jj] = wp[(size_t)(q * 8 + jj) * 64];
+    __builtin_amdgcn_sched_barrier(0);   // keep the loads above the stores below (the compiler otherwise sinks the weight loads)
+    T* sdst = lds + (tid >> 5) * LDA + (tid & 31) * 8;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) *reinterpret_cast<u32x4*>(sdst + i * 16 * LDA) = va[i];
+    __syncthreads();
+    if (dbg) dbg[1] = wall_clock64();
+    // straight-line code (rows past M are copies of row M - 1 and are dropped by the epilogue): no branch may sit between
+    // the fragment reads and the MFMAs, or every read is waited for on its own
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const T* ab = lds + nl * LDA + (kw * JQ) * 32 + g * 8;   // lane (nl, g), phase q, step jj: k = 256 q + 32 (JQ kw + jj) + 8 g .. + 7
+    // (the phase index comes as a type: with a loop variable the staging registers' indices are not constants when the
+    // compiler decides where `va` lives, and it keeps the array in scratch memory)
+    auto phase = [&](auto QC) {
+        constexpr int q = decltype(QC)::value;
+        if constexpr (q + 1 < NPH) {   // phase q + 1 -> LDS while phase q is multiplied
+#pragma unroll
+            for (int i = 0; i < NT; ++i) *reinterpret_cast<u32x4*>(sdst + i * 16 * LDA + (q + 1) * 256) = va[(q + 1) * NT + i];
+        }
+#pragma unroll
+        for (int jj = 0; jj < JQ; ++jj) {
+            const bf16x8 bfr = __builtin_bit_cast(bf16x8, wf[q * JQ + jj]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(ab + t * 16 * LDA + q * 256 + jj * 32);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // phase q + 1 is visible; after the last phase: every wave is done with the activation rows
+    };
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    if constexpr (NPH == 4) {
+        phase(std::integral_constant<int, 2>{});
+        phase(std::integral_constant<int, 3>{});
+    }
+    if (dbg) dbg[2] = wall_clock64();
+    float* red = reinterpret_cast<float*>(as_raw);   // the buffer becomes the reduction area
+    {
+        float* rb = red + (size_t)((kw * NSUB + sub) * MC) * RS + nl;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rb[(t * 16 + g * 4 + r) * RS] = acc[t][r];   // accumulator row g*4 + r, column nl
+    }
+    __syncthreads();
+    // epilogue items: (partner tile p of the block, row, column) -- NSUB / 2 * MC * 16 of them.  All the loads of a
+    // thread's items come before its first store (see rows_epilogue).
+    constexpr int ITEMS = NSUB / 2 * MC * 16;
+    constexpr int NIT = (ITEMS + 511) / 512;
+    float v0[NIT], v1[NIT];
+    EpiRow er[NIT];
+    EpiCol ec[NIT];
+    float2 cs[NIT];
+    int tile_[NIT], mi_[NIT];
+    bool ok_[NIT];
+    const int c = tid & 15;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int it = tid + 512 * i;
+        const int row = (it >> 4) % MC, p = ((it >> 4) / MC) % (NSUB / 2);
+        const int tile = blockIdx.x * (NSUB / 2) + p;
+        mi_[i] = m0 + row;
+        ok_[i] = it < ITEMS && tile < tiles32 && mi_[i] < a.M;
+        tile_[i] = tile < tiles32 ? tile : tiles32 - 1;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) {
+            s0 += red[(size_t)(((w * NSUB + 2 * p) * MC) + row) * RS + c];
+            s1 += red[(size_t)(((w * NSUB + 2 * p + 1) * MC) + row) * RS + c];
+        }
+        v0[i] = s0; v1[i] = s1;
+        er[i] = rows_pos<EPI>(a, ok_[i] ? mi_[i] : a.M);
+        ec[i] = cols_bias<EPI>(a, tile_[i], c);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) cs[i] = rope_cs<EPI>(a, tile_[i], c, er[i].pos);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+        if (ok_[i]) rows_epilogue<EPI, T>(a, tile_[i], c, mi_[i], v0[i], v1[i], kz, gridDim.z > 1, er[i], ec[i], cs[i]);
+    if (dbg) dbg[3] = wall_clock64();
+}
+
 // y[m][i] = resid[m][i] + bias[i] + sum_s part[s][m][i], s ascending (the K-split of gemm_rows_kernel).
 // grid (M, N / 256): every thread fetches its <= 8 partials at once, then adds them in order.
 __global__ __launch_bounds__(256) void fold_partials_kernel(float* __restrict__ y, const float* __restrict__ resid,
@@ -1139,6 +1293,70 @@ hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s) {
     if (e != hipSuccess || ks == 1) return e;
     if (a.ks_out != nullptr && EPI == EPI_RESID && a.resid == a.y) return e;   // the caller folds (fused into its norm launch)
     hipLaunchKernelGGL(fold_partials_kernel, dim3(a.M, (a.N + 255) / 256), dim3(256), 0, s, a.y, EPI == EPI_RESID ? a.resid : nullptr, a.part, ks,
+                       a.bias, a.M, a.N, a.ldy);
+    return hipGetLastError();
+}
+
+template <int EPI>
+inline int tiles32_of(int N) {
+    if (EPI == EPI_ROPE_KV) return (N / kHeadDim) * 2;
+    if (EPI == EPI_SWIGLU) return N / 32;
+    return (N + 31) / 32;
+}
+
+template <int EPI, int NSUB, int KB, int MC>
+hipError_t launch_gemm_as_v(const GemmArgs& a, int tiles32, int gz, hipStream_t s) {
+    constexpr int lds_a = MC * (KB + 8) * 2, lds_r = 8 * MC * kAsRedStride * 4;
+    constexpr int lds = lds_a > lds_r ? lds_a : lds_r;   // 132,096 B at KB = 1024, MC = 64
+    static bool attr_done[64] = {};   // one flag per instantiation and device
+    int dev = 0;
+    hipError_t ed = hipGetDevice(&dev);
+    if (ed != hipSuccess) return ed;
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_as_kernel<EPI, NSUB, KB, MC>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e0 != hipSuccess) return e0;
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    const dim3 grid((2 * tiles32 + NSUB - 1) / NSUB, (a.M + MC - 1) / MC, gz);
+    hipLaunchKernelGGL((gemm_as_kernel<EPI, NSUB, KB, MC>), grid, dim3(512), lds, s, a, tiles32);
+    return hipGetLastError();
+}
+
+template <int EPI, int NSUB, int KB>
+hipError_t launch_gemm_as_m(const GemmArgs& a, int tiles32, int gz, hipStream_t s) {
+    if (a.M <= 16) return launch_gemm_as_v<EPI, NSUB, KB, 16>(a, tiles32, gz, s);
+    if (a.M <= 32) return launch_gemm_as_v<EPI, NSUB, KB, 32>(a, tiles32, gz, s);
+    return launch_gemm_as_v<EPI, NSUB, KB, 64>(a, tiles32, gz, s);
+}
+
+// Activation-stationary launch, or `handled = false` when the shape is not its own (the caller falls through).
+template <int EPI>
+hipError_t launch_gemm_as(const GemmArgs& a, hipStream_t s, bool& handled) {
+    handled = false;
+    const bool splittable = (EPI == EPI_RESID || EPI == EPI_STORE) && a.part != nullptr;
+    if (EPI == EPI_SWIGLU && a.N % 32) return hipSuccess;
+    const int tiles32 = tiles32_of<EPI>(a.N), chunks = a.M <= 64 ? 1 : (a.M + 63) / 64;
+    // the block's K range: all of K (1024 or 512), or for the residual GEMMs a split into fp32 partial slabs -- 1024 k
+    // each, 512 when that leaves fewer than 192 blocks
+    int KB = 0;
+    if (a.K == 1024 || a.K == 512) KB = a.K;
+    else if (splittable && a.K % 1024 == 0) {
+        KB = 1024;
+        if ((long long)tiles32 * chunks * (a.K / 1024) < 192 && a.K / 512 <= 8) KB = 512;
+    }
+    if (KB == 0) return hipSuccess;
+    const int gz = a.K / KB;
+    if (gz > 8 || (gz > 1 && (size_t)gz * a.M * a.N > a.part_floats)) return hipSuccess;
+    const bool four = (long long)((2 * tiles32 + 3) / 4) * chunks * gz >= 192;
+    handled = true;
+    hipError_t e;
+    if (KB == 1024) e = four ? launch_gemm_as_m<EPI, 4, 1024>(a, tiles32, gz, s) : launch_gemm_as_m<EPI, 2, 1024>(a, tiles32, gz, s);
+    else e = four ? launch_gemm_as_m<EPI, 4, 512>(a, tiles32, gz, s) : launch_gemm_as_m<EPI, 2, 512>(a, tiles32, gz, s);
+    if (a.ks_out != nullptr) *a.ks_out = gz;
+    if (e != hipSuccess || gz == 1) return e;
+    if (a.ks_out != nullptr && EPI == EPI_RESID && a.resid == a.y) return e;   // the caller folds (fused into its norm launch)
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(a.M, (a.N + 255) / 256), dim3(256), 0, s, a.y, EPI == EPI_RESID ? a.resid : nullptr, a.part, gz,
                        a.bias, a.M, a.N, a.ldy);
     return hipGetLastError();
 }
@@ -1258,6 +1476,18 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
     // 16x slower than the bf16 one, so with few rows (one live wave per block) the first generation's 16-feature tiles
     // with K split over the waves win (8 rows, Turbo batched: 5156 vs 3516 tok/s)
     // 256 rows or more of bf16 operands: the register-blocked kernel (gemm_wide_kernel) where it leaves enough blocks
+    if (wdtype == 1 && a.Wf != nullptr && a.M <= kAsMaxRows) {
+        bool handled = false;
+        hipError_t e = hipSuccess;
+        switch (epilogue) {
+            case EPI_STORE: e = launch_gemm_as<EPI_STORE>(a, s, handled); break;
+            case EPI_RESID: e = launch_gemm_as<EPI_RESID>(a, s, handled); break;
+            case EPI_GELU: e = launch_gemm_as<EPI_GELU>(a, s, handled); break;
+            case EPI_SWIGLU: e = launch_gemm_as<EPI_SWIGLU>(a, s, handled); break;
+            case EPI_ROPE_KV: e = launch_gemm_as<EPI_ROPE_KV>(a, s, handled); break;
+        }
+        if (handled || e != hipSuccess) return e;
+    }
     constexpr int wide_min = 256;
     if (wdtype == 1 && a.M >= wide_min && a.K % 128 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0) &&
         gemm_wide_pays(a, epilogue)) {
@@ -1290,6 +1520,28 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
     }
     if (wdtype == 2) return launch_gemm_g<GemmBF16W>(a, epilogue, s);   // bf16 weights, fp32 activation rows
     return wdtype == 1 ? launch_gemm_g<GemmBF16>(a, epilogue, s) : launch_gemm_g<GemmF32>(a, epilogue, s);
+}
+
+size_t weight_fragment_elems(int N, int K, int epilogue) {
+    const int t = epilogue == EPI_ROPE_KV ? (N / kHeadDim) * 2 : (N + 31) / 32;
+    return (size_t)t * 32 * K;
+}
+
+hipError_t launch_weight_fragments(const void* W, void* out, int N, int K, int epilogue, hipStream_t s) {
+    if (!W || !out || N <= 0 || K <= 0 || (K & 31)) return hipErrorInvalidValue;
+    if (epilogue == EPI_ROPE_KV && N % kHeadDim) return hipErrorInvalidValue;
+    if (epilogue == EPI_SWIGLU && (N % 32)) return hipErrorInvalidValue;
+    const uint16_t* w = static_cast<const uint16_t*>(W);
+    uint16_t* o = static_cast<uint16_t*>(out);
+    const size_t blocks = weight_fragment_elems(N, K, epilogue) / 512;   // one per (sub-tile, 32-k step)
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks), block(64);
+    switch (epilogue) {
+        case EPI_ROPE_KV: hipLaunchKernelGGL(fragment_weights_kernel<EPI_ROPE_KV>, grid, block, 0, s, w, o, N, K); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL(fragment_weights_kernel<EPI_SWIGLU>, grid, block, 0, s, w, o, N, K); break;
+        default: hipLaunchKernelGGL(fragment_weights_kernel<EPI_STORE>, grid, block, 0, s, w, o, N, K); break;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_rmsnorm_rows(float* x, const float* w, float eps, void* out, int M, int d, int act_bf16, hipStream_t s,

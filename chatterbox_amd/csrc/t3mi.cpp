@@ -139,6 +139,11 @@ struct t3mi_model {
     float eps = 1e-5f;
     hipStream_t stream = nullptr;
     DevBuf wbuf, small, emb, pos_emb, rope_cos, rope_sin;
+    DevBuf wfrag;                      // bf16 models: the streamed matrices once more, fragment-major, at wbuf's offsets (build_fragments)
+    int as_mask = 15;                  // which GEMMs take it: 1 qkv, 2 o_proj, 4 gate_up / c_fc, 8 down, 16 head (T3MI_AS=<mask>, 0 = none)
+    const void* frag(const void* w, int which) const {   // the fragment-major twin of a matrix in wbuf, or nullptr
+        return (wfrag.p && (as_mask & which)) ? static_cast<const char*>(wfrag.p) + (static_cast<const char*>(w) - static_cast<const char*>(wbuf.p)) : nullptr;
+    }
     int rope_len = 0;
     std::vector<LayerW> layers;
     const float* norm_w = nullptr;
@@ -650,6 +655,37 @@ int load_turbo(t3mi_model* m, const t3mi::SafeTensorsFile& st, const char* cache
     return T3MI_OK;
 }
 
+// bf16 models keep a second, fragment-major image of every streamed matrix for the activation-stationary GEMM of
+// batches of up to t3k::kAsMaxRows rows (batch_kernels.hip, gemm_as_kernel): +1.02 GB of HBM for the 520M model, built
+// on the device in about a millisecond.  T3MI_AS=<mask> picks the GEMMs that use it (t3mi_model::as_mask; 0 = none, the LDS-staged kernels then serve those
+// batches; the head is not in the default: measured no faster there).
+int build_fragments(t3mi_model* m) {
+    if (m->wdtype != T3MI_W_BF16) return T3MI_OK;
+    if (const char* e = std::getenv("T3MI_AS")) m->as_mask = std::atoi(e) & 31;
+    if (m->as_mask == 0) return T3MI_OK;
+    const int d = m->d, F = m->F, V = m->V;
+    const bool turbo = m->variant == T3MI_VARIANT_TURBO;
+    if (d % 32 || F % 32) return T3MI_OK;
+    // every per-layer matrix has a whole number of 32-feature tiles, so its fragment image has its size; the head (last
+    // in wbuf) is rounded up to one
+    const size_t head_off = static_cast<const char*>(m->head_w) - m->wbuf.as<char>();
+    const size_t need = head_off + t3k::weight_fragment_elems(V, d, t3k::EPI_STORE) * 2;
+    HIPCHK(hipDeviceSynchronize());   // the uploads and conversions into wbuf
+    HIPCHK(m->wfrag.alloc(need));
+    auto put = [&](const void* w, int N, int K, int epi) -> hipError_t {
+        return t3k::launch_weight_fragments(w, const_cast<void*>(m->frag(w, 31)), N, K, epi, m->stream);
+    };
+    for (const LayerW& lw : m->layers) {
+        HIPCHK(put(lw.wqkv, 3 * d, d, t3k::EPI_ROPE_KV));
+        HIPCHK(put(lw.wo, d, d, t3k::EPI_RESID));
+        HIPCHK(put(lw.wgu, turbo ? F : 2 * F, d, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU));
+        HIPCHK(put(lw.wdown, d, F, t3k::EPI_RESID));
+    }
+    HIPCHK(put(m->head_w, V, d, t3k::EPI_STORE));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return T3MI_OK;
+}
+
 // ---- one transformer pass over the rows currently in sess->x ------------------------------------
 #ifdef T3K_STAMPS
 unsigned long long* g_stamp_buf = nullptr;   // [launch][T3K_STAMP_WAVES][T3K_STAMP_SLOTS]
@@ -810,7 +846,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
         c.pend_ks = 0;
         {
             t3k::GemmArgs a;
-            a.W = lw.wqkv; a.A = c.xn; a.M = c.M; a.N = 3 * d; a.K = d;
+            a.W = lw.wqkv; a.Wf = m->frag(lw.wqkv, 1); a.A = c.xn; a.M = c.M; a.N = 3 * d; a.K = d;
             a.posmap = c.posmap; a.rowmap = c.rowmap;
             a.rope_cos = m->rope_cos.as<float>(); a.rope_sin = m->rope_sin.as<float>();
             a.q = c.q; a.kcache = kc; a.vcache = vc; a.kv_bf16 = s->kv_bf16 ? 1 : 0; a.n_heads = H; a.max_len = s->max_len;
@@ -828,7 +864,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
         if (tm) tm->mark(K_ATTN);
         {
             t3k::GemmArgs a;
-            a.W = lw.wo; a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
+            a.W = lw.wo; a.Wf = m->frag(lw.wo, 2); a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
             a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_o;
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
             int ks = 1;
@@ -843,14 +879,14 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
         c.pend_ks = 0;
         {
             t3k::GemmArgs a;
-            a.W = lw.wgu; a.A = c.xn; a.M = c.M; a.N = turbo ? F : 2 * F; a.K = d; a.yact = c.hact;
+            a.W = lw.wgu; a.Wf = m->frag(lw.wgu, 4); a.A = c.xn; a.M = c.M; a.N = turbo ? F : 2 * F; a.K = d; a.yact = c.hact;
             a.bias = lw.b_fc;
             HIPCHK(t3k::launch_gemm(a, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, wdt, st));
         }
         if (tm) tm->mark(K_GATEUP);
         {
             t3k::GemmArgs a;
-            a.W = lw.wdown; a.A = c.hact; a.M = c.M; a.N = d; a.K = F;
+            a.W = lw.wdown; a.Wf = m->frag(lw.wdown, 8); a.A = c.hact; a.M = c.M; a.N = d; a.K = F;
             a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_down;
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
             int ks = 1;
@@ -893,7 +929,7 @@ int run_head(t3mi_model* m, Session* s, StepTimer* tm) {
                                             s->gpart.as<float>(), s->pend_ks, s->pend_bias));
         s->pend_ks = 0;
         t3k::GemmArgs a;
-        a.W = m->head_w; a.A = s->xn.p; a.M = s->rows; a.N = m->V; a.K = d;
+        a.W = m->head_w; a.Wf = m->frag(m->head_w, 16); a.A = s->xn.p; a.M = s->rows; a.N = m->V; a.K = d;
         a.y = s->logits.as<float>(); a.ldy = m->V; a.bias = m->head_b;
         HIPCHK(t3k::launch_gemm(a, t3k::EPI_STORE, m->wdtype, m->stream));
         if (tm) tm->mark(K_HEAD);
@@ -1072,6 +1108,7 @@ int t3mi_open_cached(const char* path, int variant, int device, int wdtype, cons
     HIPCHK(static_scratch(device, &m->static_scratch));   // once per device, with that device current
     HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     int rc = variant == T3MI_VARIANT_TURBO ? load_turbo(m.get(), st, cache_path) : load_llama(m.get(), st, cache_path);
+    if (!rc) rc = build_fragments(m.get());
     if (rc) {
         (void)hipStreamDestroy(m->stream);
         return rc;

@@ -1,14 +1,32 @@
-// Micro-benchmark of the many-row bf16 GEMM (batch_kernels.hip) on the decode shapes at M = 128, cold weights.
+// Micro-benchmark of the many-row bf16 GEMMs (batch_kernels.hip) on the decode shapes at M rows, cold weights:
+// the LDS-staged kernel (gemm_rows_kernel / gemm_wide_kernel) against the activation-stationary one (gemm_as_kernel,
+// fragment-major weights), with the two outputs compared on random operands.
 // Build (from the repo root, after `make -C chatterbox_amd/csrc`):
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -x hip scripts/micro/gemm_micro.cpp chatterbox_amd/csrc/batch_kernels.o -o scripts/micro/gemm_micro
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -x hip scripts/micro/gemm_micro.cpp -x none chatterbox_amd/csrc/batch_kernels.o -o scripts/micro/gemm_micro
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../chatterbox_amd/csrc/kernels.hpp"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("ERR %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+static uint16_t f2bf_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf2f_host(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
 
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 128;
@@ -17,19 +35,37 @@ int main(int argc, char** argv) {
     CK(hipStreamCreate(&st));
     const int NCOPY = 24;   // rotate through copies so the weights are never cached
     const size_t wmax = (size_t)8448 * d;    // elements of the largest matrix (head: 8194 rows; gate_up: 8192), padded
-    uint16_t *W, *A, *yact;
-    float *y, *q, *kc, *vc, *part, *cosv, *sinv;
+    uint16_t *W, *Wf, *A, *yact[2];
+    float *y[2], *q[2], *kc[2], *vc[2], *part, *cosv, *sinv;
     int* pos;
     unsigned long long* dbg;
-    CK(hipMalloc(&W, wmax * 2 * NCOPY)); CK(hipMemset(W, 0, wmax * 2 * NCOPY));
-    CK(hipMalloc(&A, (size_t)M * F * 2)); CK(hipMemset(A, 0, (size_t)M * F * 2));
-    CK(hipMalloc(&yact, (size_t)M * F * 2));
-    CK(hipMalloc(&y, (size_t)M * 8200 * 4)); CK(hipMemset(y, 0, (size_t)M * 8200 * 4));
-    CK(hipMalloc(&q, (size_t)M * d * 4));
-    CK(hipMalloc(&kc, (size_t)M * H * max_len * 64 * 4)); CK(hipMalloc(&vc, (size_t)M * H * max_len * 64 * 4));
+    CK(hipMalloc(&W, wmax * 2 * NCOPY));
+    CK(hipMalloc(&Wf, wmax * 2 * NCOPY));
+    CK(hipMalloc(&A, (size_t)M * F * 2));
+    {
+        srand(1);
+        std::vector<uint16_t> hw(wmax), ha((size_t)M * F);
+        for (auto& v : hw) v = f2bf_host((rand() / (float)RAND_MAX - 0.5f) * 0.1f);
+        for (auto& v : ha) v = f2bf_host((rand() / (float)RAND_MAX - 0.5f) * 2.0f);
+        for (int c = 0; c < NCOPY; ++c) CK(hipMemcpy(W + (size_t)c * wmax, hw.data(), wmax * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+    }
+    const size_t kvn = (size_t)M * H * max_len * 64;
+    for (int v = 0; v < 2; ++v) {
+        CK(hipMalloc(&yact[v], (size_t)M * F * 2)); CK(hipMemset(yact[v], 0, (size_t)M * F * 2));
+        CK(hipMalloc(&y[v], (size_t)M * 8200 * 4));
+        CK(hipMalloc(&q[v], (size_t)M * d * 4)); CK(hipMemset(q[v], 0, (size_t)M * d * 4));
+        CK(hipMalloc(&kc[v], kvn * 4)); CK(hipMalloc(&vc[v], kvn * 4));
+        CK(hipMemset(kc[v], 0, kvn * 4)); CK(hipMemset(vc[v], 0, kvn * 4));
+    }
     CK(hipMalloc(&part, (size_t)8 * M * d * 4));
     CK(hipMalloc(&cosv, max_len * 64 * 4)); CK(hipMalloc(&sinv, max_len * 64 * 4));
-    CK(hipMemset(cosv, 0, max_len * 64 * 4)); CK(hipMemset(sinv, 0, max_len * 64 * 4));
+    {
+        std::vector<float> hc(max_len * 64), hs(max_len * 64);
+        for (int i = 0; i < max_len * 64; ++i) { hc[i] = cosf(i * 0.37f); hs[i] = sinf(i * 0.37f); }
+        CK(hipMemcpy(cosv, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(sinv, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    }
     CK(hipMalloc(&pos, M * 4));
     std::vector<int> hp(M);
     for (int i = 0; i < M; ++i) hp[i] = 100 + (i % 50);
@@ -42,48 +78,101 @@ int main(int argc, char** argv) {
                           {"gate_up_swiglu", t3k::EPI_SWIGLU, 2 * F, d}, {"down_resid", t3k::EPI_RESID, d, F},
                           {"head_store", t3k::EPI_STORE, 8194, d}};
     for (const Case& c : cases) {
-        auto launch = [&](int i, unsigned long long* dg) {
-            t3k::GemmArgs a;
-            a.W = W + (size_t)(i % NCOPY) * wmax; a.A = A; a.M = M; a.N = c.N; a.K = c.K;
-            a.y = y; a.resid = y; a.ldy = c.epi == t3k::EPI_STORE ? c.N : d; a.yact = yact;
-            a.posmap = pos; a.rope_cos = cosv; a.rope_sin = sinv; a.q = q; a.kcache = kc; a.vcache = vc;
-            a.n_heads = H; a.max_len = max_len; a.part = part; a.part_floats = (size_t)8 * M * d; a.dbg = dg;
-            return t3k::launch_gemm(a, c.epi, 1, st);
+        for (int i = 0; i < NCOPY; ++i)
+            CK(t3k::launch_weight_fragments(W + (size_t)i * wmax, Wf + (size_t)i * wmax, c.N, c.K, c.epi, st));
+        CK(hipStreamSynchronize(st));
+        if (t3k::weight_fragment_elems(c.N, c.K, c.epi) > wmax) { printf("fragment copy too large\n"); return 1; }
+        for (int v = 0; v < 2; ++v) {   // v = 0: LDS-staged kernels, v = 1: activation-stationary
+            auto launch = [&](int i, unsigned long long* dg) {
+                t3k::GemmArgs a;
+                a.W = W + (size_t)(i % NCOPY) * wmax; a.A = A; a.M = M; a.N = c.N; a.K = c.K;
+                a.Wf = v ? Wf + (size_t)(i % NCOPY) * wmax : nullptr;
+                a.y = y[v]; a.resid = y[v]; a.ldy = c.epi == t3k::EPI_STORE ? c.N : d; a.yact = yact[v];
+                a.posmap = pos; a.rope_cos = cosv; a.rope_sin = sinv; a.q = q[v]; a.kcache = kc[v]; a.vcache = vc[v];
+                a.n_heads = H; a.max_len = max_len; a.part = part; a.part_floats = (size_t)8 * M * d; a.dbg = dg;
+                return t3k::launch_gemm(a, c.epi, 1, st);
+            };
+            for (int i = 0; i < 30; ++i) CK(launch(i, nullptr));
+            CK(hipStreamSynchronize(st));
+            const int n = 240;
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < n; ++i) CK(launch(i, nullptr));
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            CK(hipMemset(dbg, 0, 4096 * 4 * 8));
+            CK(hipMemset(y[v], 0, (size_t)M * 8200 * 4));   // residual input 0: y = the product
+            CK(launch(7, dbg));
+            CK(hipStreamSynchronize(st));
+            std::vector<unsigned long long> h(4096 * 4);
+            CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, tend = 0;
+            std::vector<double> p1, p2, p3;
+            int nb = 0;
+            for (int b = 0; b < 4096; ++b) {
+                if (!h[4 * b]) continue;
+                nb++;
+                t0 = std::min(t0, h[4 * b]);
+                tend = std::max(tend, std::max(h[4 * b + 2], h[4 * b + 3]));
+            }
+            for (int b = 0; b < 4096; ++b) {
+                if (!h[4 * b]) continue;
+                p1.push_back((h[4 * b + 1] - t0) * 0.01);
+                p2.push_back((h[4 * b + 2] - t0) * 0.01);
+                if (h[4 * b + 3]) p3.push_back((h[4 * b + 3] - t0) * 0.01);
+            }
+            auto med = [](std::vector<double>& x) { if (x.empty()) return 0.0; std::sort(x.begin(), x.end()); return x[x.size() / 2]; };
+            const double wmb = (double)c.N * c.K * 2 / 1e6;
+            printf("%-16s %s M=%d N=%d K=%d  %7.2f us/launch (back to back, incl. fold)  W %.1f MB -> %.0f GB/s | blocks %d: operands ready %.2f, "
+                   "loop done %.2f, epilogue done %.2f (median us after first block start), last block end %.2f\n",
+                   c.name, v ? "AS  " : "rows", M, c.N, c.K, ms * 1e3 / n, wmb, wmb / (ms * 1e3 / n) * 1e3, nb, med(p1), med(p2), med(p3),
+                   (tend - t0) * 0.01);
+        }
+        // the two paths sum the same products in different orders: compare against the output's scale
+        auto cmp_f32 = [&](const float* a0, const float* a1, size_t n, const char* what) -> int {
+            std::vector<float> h0(n), h1(n);
+            CK(hipMemcpy(h0.data(), a0, n * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h1.data(), a1, n * 4, hipMemcpyDeviceToHost));
+            double mx = 0, sc = 0;
+            size_t at = 0, nbad = 0;
+            for (size_t i = 0; i < n; ++i) {
+                const double df = fabsf(h0[i] - h1[i]);
+                if (df > mx) { mx = df; at = i; }
+                if (df > 1e-4 && nbad < 6) printf("      element %zu: %.6f vs %.6f\n", i, h0[i], h1[i]);
+                nbad += df > 1e-4;
+                sc = std::max(sc, (double)fabsf(h0[i]));
+            }
+            printf("    %-10s max |diff| %.3g at element %zu (%zu elements off by more than 1e-4; max |value| %.3g)%s\n", what, mx, at, nbad, sc,
+                   (sc > 0 && mx <= 2e-5 * sc + 1e-6) ? "" : "  <-- MISMATCH");
+            return 0;
         };
-        for (int i = 0; i < 30; ++i) CK(launch(i, nullptr));
-        CK(hipStreamSynchronize(st));
-        const int n = 240;
-        CK(hipEventRecord(e0, st));
-        for (int i = 0; i < n; ++i) CK(launch(i, nullptr));
-        CK(hipEventRecord(e1, st));
-        CK(hipEventSynchronize(e1));
-        float ms;
-        CK(hipEventElapsedTime(&ms, e0, e1));
-        CK(hipMemset(dbg, 0, 4096 * 4 * 8));
-        CK(launch(7, dbg));
-        CK(hipStreamSynchronize(st));
-        std::vector<unsigned long long> h(4096 * 4);
-        CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull, tend = 0;
-        std::vector<double> p1, p2, p3;
-        int nb = 0;
-        for (int b = 0; b < 4096; ++b) {
-            if (!h[4 * b]) continue;
-            nb++;
-            t0 = std::min(t0, h[4 * b]);
-            tend = std::max(tend, std::max(h[4 * b + 2], h[4 * b + 3]));
+        auto cmp_bf16 = [&](const uint16_t* a0, const uint16_t* a1, size_t n, const char* what) -> int {
+            std::vector<uint16_t> h0(n), h1(n);
+            CK(hipMemcpy(h0.data(), a0, n * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h1.data(), a1, n * 2, hipMemcpyDeviceToHost));
+            double mx = 0, sc = 0;
+            size_t nd = 0;
+            for (size_t i = 0; i < n; ++i) {
+                const double x0 = bf2f_host(h0[i]), x1 = bf2f_host(h1[i]);
+                mx = std::max(mx, fabs(x0 - x1)); sc = std::max(sc, fabs(x0));
+                nd += h0[i] != h1[i];
+            }
+            printf("    %-10s max |diff| %.3g  (max |value| %.3g), %zu of %zu bf16 values differ%s\n", what, mx, sc, nd, n,
+                   (sc > 0 && mx <= 0.01 * sc) ? "" : "  <-- MISMATCH");
+            return 0;
+        };
+        if (c.epi == t3k::EPI_STORE) cmp_f32(y[0], y[1], (size_t)M * c.N, "logits");
+        if (c.epi == t3k::EPI_RESID) {
+            // K-split launches leave the fold to the caller here only when ks_out is set; it is not: y holds the result
+            cmp_f32(y[0], y[1], (size_t)M * d, "x");
         }
-        for (int b = 0; b < 4096; ++b) {
-            if (!h[4 * b]) continue;
-            p1.push_back((h[4 * b + 1] - t0) * 0.01);
-            p2.push_back((h[4 * b + 2] - t0) * 0.01);
-            if (h[4 * b + 3]) p3.push_back((h[4 * b + 3] - t0) * 0.01);
+        if (c.epi == t3k::EPI_SWIGLU) cmp_bf16(yact[0], yact[1], (size_t)M * F, "hact");
+        if (c.epi == t3k::EPI_ROPE_KV) {
+            cmp_f32(q[0], q[1], (size_t)M * d, "q");
+            cmp_f32(kc[0], kc[1], kvn, "k cache");
+            cmp_f32(vc[0], vc[1], kvn, "v cache");
         }
-        auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
-        const double wmb = (double)c.N * c.K * 2 / 1e6;
-        printf("%-16s M=%d N=%d K=%d  %7.2f us/launch (back to back, incl. fold)  W %.1f MB -> %.0f GB/s | blocks %d: first tile in LDS %.2f, loop done %.2f, "
-               "epilogue done %.2f (median us after first block start), last block end %.2f\n",
-               c.name, M, c.N, c.K, ms * 1e3 / n, wmb, wmb / (ms * 1e3 / n) * 1e3, nb, med(p1), med(p2), med(p3), (tend - t0) * 0.01);
     }
     return 0;
 }

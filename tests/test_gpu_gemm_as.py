@@ -1,0 +1,103 @@
+"""The activation-stationary bf16 GEMM (batch_kernels.hip, gemm_as_kernel; fragment-major weight copy) against the
+LDS-staged kernels it replaces for batches of up to 128 rows, and against the fp32 path.
+
+The two bf16 kernels multiply the same bf16 operands and accumulate in fp32; they differ only in the order of the
+sums (K slices per wave, reduced in LDS).  A sum that differs in its last fp32 bit can flip the bf16 rounding of an
+activation (1 part in 256), and 30 layers carry such flips forward, so the two bf16 paths agree to AS_VS_STAGED_TOL of
+max |logit| (half the bf16 bar; measured up to 0.7 %), and each stays inside the bf16 bar against the fp32 path, the
+new kernel no further from it than the old one (within 1.5x).  Every shape class of the launch heuristic is covered: 16-, 32- and 64-row chunks, one chunk and two, the
+K-split residual GEMM with 1024-k and 512-k slabs (d_ff 4096 at full size, K = 1024 unsplit at tiny size), the
+4- and 2-sub-tile blocks, a head whose vocabulary is not a multiple of 32 (mask 16: last tile partly empty), and
+Turbo's bias / GELU / no-RoPE epilogues."""
+import os
+
+import numpy as np
+import pytest
+
+import chatterbox_amd as cb
+from chatterbox_amd import synth
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+AS_VS_STAGED_TOL = 1.5e-2   # same bf16 operands, different summation order
+BF16_LOGIT_TOL = 3e-2     # against the fp32 path (tests/test_gpu_scale.py)
+
+
+def _open(path, turbo, mask, dims, dtype="bf16"):
+    old = os.environ.get("T3MI_AS")
+    os.environ["T3MI_AS"] = str(mask)     # read once, when the model is opened
+    try:
+        return (cb.load_t3_turbo if turbo else cb.load_t3)(path, device=0, dtype=dtype, start_speech_token=dims.start_speech_token,
+                                                           stop_speech_token=dims.stop_speech_token)
+    finally:
+        if old is None:
+            del os.environ["T3MI_AS"]
+        else:
+            os.environ["T3MI_AS"] = old
+
+
+def _run(model, embs, n, forced=None):
+    kw = dict(max_new_tokens=n + 2, top_p=0.0, mask_stop=True)
+    if forced is not None:
+        kw["forced"] = forced
+    out = []
+    with cb.Session(model, embs, **kw) as s:
+        out.append(s.logits())
+        for _ in range(n):
+            s.decode(1)
+            out.append(s.logits())
+        toks = np.array([s.tokens(u)[:n + 1] for u in range(len(embs))])   # Turbo: n + 1 (the first comes from the prefill)
+    return out, toks
+
+
+CASES = [
+    # (name, turbo, dims, utterances): llama rows = 2 x utterances, Turbo rows = utterances
+    ("llama-tiny", False, synth.TINY, [3, 12, 24, 40, 64]),
+    ("llama-full", False, synth.FULL, [5, 16, 30, 44]),
+    ("turbo-tiny", True, synth.TURBO_TINY, [7, 24, 50, 100]),
+]
+
+
+@pytest.mark.parametrize("name,turbo,dims,utts", CASES, ids=[c[0] for c in CASES])
+def test_activation_stationary_gemm_equals_staged_gemm(name, turbo, dims, utts):
+    path = synth.ensure_turbo_checkpoint(dims, 4321) if turbo else synth.ensure_checkpoint(dims, 1234)
+    n = 3
+    rpu = 1 if turbo else 2
+    m32 = _open(path, turbo, 0, dims, dtype="f32")
+    staged = _open(path, turbo, 0, dims)
+    as_all = _open(path, turbo, 31, dims)      # every GEMM, the head included
+    as_dflt = _open(path, turbo, 13, dims)     # the default set
+    try:
+        for U in utts:
+            embs = [synth.synth_embeds(rpu, 9 + (u % 5), dims.hidden_size, 700 + u) for u in range(U)]
+            ref, forced = _run(m32, embs, n)
+            a, _ = _run(staged, embs, n, forced)
+            b, _ = _run(as_all, embs, n, forced)
+            c, _ = _run(as_dflt, embs, n, forced)
+            for i in range(n + 1):
+                assert np.isfinite(b[i]).all() and np.isfinite(c[i]).all()
+                assert rel_err(b[i], a[i]) < AS_VS_STAGED_TOL, (name, U, i, rel_err(b[i], a[i]))
+                assert rel_err(c[i], a[i]) < AS_VS_STAGED_TOL, (name, U, i, rel_err(c[i], a[i]))
+                eb, ea = rel_err(b[i], ref[i]), rel_err(a[i], ref[i])
+                assert eb < BF16_LOGIT_TOL and eb < 1.5 * ea + 1e-3, (name, U, i, eb, ea)
+    finally:
+        for m in (m32, staged, as_all, as_dflt):
+            m.close()
+
+
+def test_activation_stationary_gemm_is_deterministic():
+    """The K slices meet in LDS in a fixed order and the K-split slabs are folded in a fixed order: two sessions over
+    the same batch give bit-identical logits."""
+    dims = synth.FULL
+    path = synth.ensure_checkpoint(dims, 1234)
+    embs = [synth.synth_embeds(2, 20, dims.hidden_size, 40 + u) for u in range(40)]
+    m = _open(path, False, 31, dims)
+    try:
+        a, ta = _run(m, embs, 4)
+        b, tb = _run(m, embs, 4)
+        assert np.array_equal(ta, tb)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    finally:
+        m.close()
