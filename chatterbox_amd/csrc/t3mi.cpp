@@ -140,7 +140,7 @@ struct t3mi_model {
     hipStream_t stream = nullptr;
     DevBuf wbuf, small, emb, pos_emb, rope_cos, rope_sin;
     DevBuf wfrag;                      // bf16 models: the streamed matrices once more, fragment-major, at wbuf's offsets (build_fragments)
-    int as_mask = 15;                  // which GEMMs take it: 1 qkv, 2 o_proj, 4 gate_up / c_fc, 8 down, 16 head (T3MI_AS=<mask>, 0 = none)
+    int as_mask = 13;                  // which GEMMs take it: 1 qkv, 2 o_proj, 4 gate_up / c_fc, 8 down, 16 head (T3MI_AS=<mask>, 0 = none)
     const void* frag(const void* w, int which) const {   // the fragment-major twin of a matrix in wbuf, or nullptr
         return (wfrag.p && (as_mask & which)) ? static_cast<const char*>(wfrag.p) + (static_cast<const char*>(w) - static_cast<const char*>(wbuf.p)) : nullptr;
     }
