@@ -1044,16 +1044,22 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a, int tiles32,
 
 // ---- bf16 many-row GEMM, third generation: activation-stationary, for <= 128 rows --------------------------------
 // gemm_rows_kernel stages activations AND weights through LDS once per 128-k step, with a block barrier per step:
-// at 64-128 rows it is bound by LDS traffic and by the barriers, not by HBM.  Here the 64 activation rows of a block
-// (64 x KB bf16, KB = 1024: 128 KB) go to LDS ONCE and stay; the weights never touch LDS: they are read from a
-// FRAGMENT-MAJOR copy of the matrix (fragment_weights_kernel: the 64 x 16 B of one MFMA B operand -- 16 features x 32 k
-// -- are contiguous, so a wave's load of one fragment is one 1 KB run), straight into the registers the MFMA takes.
-// A block owns NSUB sub-tiles of 16 features (NSUB / 2 partner tiles of 32, as tile32_feature lays them out) and its
-// 8 waves are NSUB sub-tiles x KW = 8 / NSUB slices of the block's K range: wave (sub, kw) holds 4 accumulator tiles
-// (64 rows x 16 features), issues all JW = KB / 32 / KW weight fragments of its slice at kernel start (they arrive
-// while the activations are staged), and after the one barrier runs JW x 4 MFMAs on fragments read from LDS.  The
-// slices' accumulators meet in LDS (fixed order kw = 0, 1, ..: deterministic), where the partner sub-tiles also meet
-// for the fused epilogues.  K > KB (down_proj) is split over blockIdx.z into the fp32 partial slabs the row norms fold.
+// at <= 128 rows it is bound by LDS traffic and by the barriers, not by HBM.  Here the MC activation rows of a block
+// (MC = 16 or 32 rows x KB k bf16; 32 x 1024: 64 KB) go to LDS ONCE and stay; the weights never touch LDS: they are
+// read from a FRAGMENT-MAJOR copy of the matrix (fragment_weights_kernel: the 64 x 16 B of one MFMA B operand -- 16
+// features x 32 k -- are contiguous, so a wave's load of one fragment is one 1 KB run), straight into the registers the
+// MFMA takes.  A block owns NSUB sub-tiles of 16 features (NSUB / 2 partner tiles of 32, as tile32_feature lays them
+// out) and its 8 waves are NSUB sub-tiles x KW = 8 / NSUB slices of K: wave (sub, kw) holds MC / 16 accumulator tiles
+// (MC rows x 16 features).  Every global load of the kernel is issued at its start -- activation pieces first, then all
+// JW = KB / 32 / KW weight fragments of the wave -- and the activation rows reach LDS in phases of 256 k: phase q + 1 is
+// written while phase q is multiplied (one barrier per phase, no buffer reuse).  The K slices' accumulators meet in LDS
+// (fixed order kw = 0, 1, ..: deterministic), where the partner sub-tiles also meet for the fused epilogues.  K > KB
+// (down_proj) is split over blockIdx.z into the fp32 partial slabs the row norms fold.
+// Measured (scripts/micro/gemm_micro.cpp, 128 rows, cold weights, back to back): qkv 7.9 -> 6.3 us, gate_up 10.8 -> 8.8,
+// down 10.0 -> 8.1 against gemm_rows_kernel; the 400-step session at 64 utterances 2.017 -> 1.845 ms per step, at 8
+// utterances 1.147 -> 0.980.  Two things the first version got wrong, both visible only in the ISA: a run-time
+// `if (tile < live tiles)` around the MFMAs made every LDS read wait on its own (loop 8.3 us instead of 2.4), and a
+// staging array of HIP's uint4 STRUCT stayed in scratch memory (copied with memcpy; the native vector type does not).
 template <int EPI>
 __global__ __launch_bounds__(64) void fragment_weights_kernel(const uint16_t* __restrict__ W, uint16_t* __restrict__ out, int N, int K) {
     const int ksteps = K >> 5;
@@ -1323,11 +1329,20 @@ hipError_t launch_gemm_as_v(const GemmArgs& a, int tiles32, int gz, hipStream_t 
     return hipGetLastError();
 }
 
+constexpr int kAsMinBlocks = 192;   // sub-tiles per block and K range per block are chosen to leave at least this many blocks
+
+// Rows per block of the activation-stationary kernel: 16 up to 32 rows, else 32.  Measured over 400-step sessions (bf16,
+// ms per step, chunks of 64 / 32 / 16 rows): 128 rows 1.895 / 1.852 / 1.930, 96 rows 1.710 / 1.656 / 1.707, 64 rows
+// 1.456 / 1.354 / 1.386, 48 rows 1.353 / 1.263 / 1.298, 32 rows 1.236 / 1.136 / 1.112, 16 rows 1.118 / 1.017 / 0.981:
+// smaller chunks put more blocks in flight (two 66 KB blocks fit a CU) and shorten the staging each block waits for;
+// the weights are re-requested once per chunk, but from L2.  (kAsMinBlocks 128 / 192 / 320 / 512: 192 is best or tied at
+// every batch size.)
+inline int as_chunk_rows(int M) { return M <= 32 ? 16 : 32; }
+
 template <int EPI, int NSUB, int KB>
 hipError_t launch_gemm_as_m(const GemmArgs& a, int tiles32, int gz, hipStream_t s) {
-    if (a.M <= 16) return launch_gemm_as_v<EPI, NSUB, KB, 16>(a, tiles32, gz, s);
-    if (a.M <= 32) return launch_gemm_as_v<EPI, NSUB, KB, 32>(a, tiles32, gz, s);
-    return launch_gemm_as_v<EPI, NSUB, KB, 64>(a, tiles32, gz, s);
+    if (as_chunk_rows(a.M) == 16) return launch_gemm_as_v<EPI, NSUB, KB, 16>(a, tiles32, gz, s);
+    return launch_gemm_as_v<EPI, NSUB, KB, 32>(a, tiles32, gz, s);
 }
 
 // Activation-stationary launch, or `handled = false` when the shape is not its own (the caller falls through).
@@ -1336,19 +1351,20 @@ hipError_t launch_gemm_as(const GemmArgs& a, hipStream_t s, bool& handled) {
     handled = false;
     const bool splittable = (EPI == EPI_RESID || EPI == EPI_STORE) && a.part != nullptr;
     if (EPI == EPI_SWIGLU && a.N % 32) return hipSuccess;
-    const int tiles32 = tiles32_of<EPI>(a.N), chunks = a.M <= 64 ? 1 : (a.M + 63) / 64;
+    const int mc = as_chunk_rows(a.M);
+    const int tiles32 = tiles32_of<EPI>(a.N), chunks = (a.M + mc - 1) / mc;
     // the block's K range: all of K (1024 or 512), or for the residual GEMMs a split into fp32 partial slabs -- 1024 k
     // each, 512 when that leaves fewer than 192 blocks
     int KB = 0;
     if (a.K == 1024 || a.K == 512) KB = a.K;
     else if (splittable && a.K % 1024 == 0) {
         KB = 1024;
-        if ((long long)tiles32 * chunks * (a.K / 1024) < 192 && a.K / 512 <= 8) KB = 512;
+        if ((long long)tiles32 * chunks * (a.K / 1024) < kAsMinBlocks && a.K / 512 <= 8) KB = 512;
     }
     if (KB == 0) return hipSuccess;
     const int gz = a.K / KB;
     if (gz > 8 || (gz > 1 && (size_t)gz * a.M * a.N > a.part_floats)) return hipSuccess;
-    const bool four = (long long)((2 * tiles32 + 3) / 4) * chunks * gz >= 192;
+    const bool four = (long long)((2 * tiles32 + 3) / 4) * chunks * gz >= kAsMinBlocks;
     handled = true;
     hipError_t e;
     if (KB == 1024) e = four ? launch_gemm_as_m<EPI, 4, 1024>(a, tiles32, gz, s) : launch_gemm_as_m<EPI, 2, 1024>(a, tiles32, gz, s);
