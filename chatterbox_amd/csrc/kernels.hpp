@@ -160,7 +160,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
 // Fragment-major copy of a bf16 matrix W [N, K] for the activation-stationary GEMM (<= kAsMaxRows rows; GemmArgs::Wf):
 // per 16-feature sub-tile (in the partner order of `epilogue`) and 32-k step, the 64 x 16 B of one MFMA operand.
 // weight_fragment_elems = bf16 elements of the copy (N rounded up to whole 32-feature tiles).
-constexpr int kAsMaxRows = 128;
+constexpr int kAsMaxRows = 1024;
 size_t weight_fragment_elems(int N, int K, int epilogue);
 hipError_t launch_weight_fragments(const void* W, void* out, int N, int K, int epilogue, hipStream_t s);
 // row norms of the many-row path; with ks > 0 they first complete x from the K-split partial slabs of the residual

@@ -140,9 +140,26 @@ struct t3mi_model {
     hipStream_t stream = nullptr;
     DevBuf wbuf, small, emb, pos_emb, rope_cos, rope_sin;
     DevBuf wfrag;                      // bf16 models: the streamed matrices once more, fragment-major, at wbuf's offsets (build_fragments)
-    int as_mask = 13;                  // which GEMMs take it: 1 qkv, 2 o_proj, 4 gate_up / c_fc, 8 down, 16 head (T3MI_AS=<mask>, 0 = none)
-    const void* frag(const void* w, int which) const {   // the fragment-major twin of a matrix in wbuf, or nullptr
-        return (wfrag.p && (as_mask & which)) ? static_cast<const char*>(wfrag.p) + (static_cast<const char*>(w) - static_cast<const char*>(wbuf.p)) : nullptr;
+    int as_mask = 15;                  // which GEMMs may take it: 1 qkv, 2 o_proj, 4 gate_up / c_fc, 8 down, 16 head
+    bool as_forced = false;            // T3MI_AS=<mask> set: exactly the named GEMMs take it at every row count the kernel accepts (tests, A/B runs)
+    // The fragment-major twin of a matrix in wbuf for a launch of M rows, or nullptr (the LDS-staged kernels then run).
+    // Row ranges per GEMM, measured over 400-step bf16 sessions (profiles/r02_gemm_as_ab.txt): qkv wins up to 1024 rows,
+    // gate_up up to 512, down up to 384 (at 512 it loses 0.1 ms per step), o_proj from 96 rows (below, its K-split
+    // LDS-staged form is 1 % ahead) to 512; the head only when T3MI_AS names it (no faster at any size).
+    const void* frag(const void* w, int which, int M) const {
+        if (!wfrag.p || !(as_mask & which)) return nullptr;
+        int lo = 1, hi = 0;
+        if (as_forced) which = 0;   // no tuned range: the kernel's own limit
+        switch (which) {
+            case 1: hi = 1024; break;
+            case 2: lo = 96; hi = 512; break;
+            case 4: hi = 512; break;
+            case 8: hi = 384; break;
+            case 16: hi = 128; break;
+            default: hi = t3k::kAsMaxRows; break;
+        }
+        if (M < lo || M > hi) return nullptr;
+        return static_cast<const char*>(wfrag.p) + (static_cast<const char*>(w) - static_cast<const char*>(wbuf.p));
     }
     int rope_len = 0;
     std::vector<LayerW> layers;
@@ -661,7 +678,10 @@ int load_turbo(t3mi_model* m, const t3mi::SafeTensorsFile& st, const char* cache
 // batches; the head is not in the default: measured no faster there).
 int build_fragments(t3mi_model* m) {
     if (m->wdtype != T3MI_W_BF16) return T3MI_OK;
-    if (const char* e = std::getenv("T3MI_AS")) m->as_mask = std::atoi(e) & 31;
+    if (const char* e = std::getenv("T3MI_AS")) {
+        m->as_mask = std::atoi(e) & 31;
+        m->as_forced = true;
+    }
     if (m->as_mask == 0) return T3MI_OK;
     const int d = m->d, F = m->F, V = m->V;
     const bool turbo = m->variant == T3MI_VARIANT_TURBO;
@@ -673,7 +693,7 @@ int build_fragments(t3mi_model* m) {
     HIPCHK(hipDeviceSynchronize());   // the uploads and conversions into wbuf
     HIPCHK(m->wfrag.alloc(need));
     auto put = [&](const void* w, int N, int K, int epi) -> hipError_t {
-        return t3k::launch_weight_fragments(w, const_cast<void*>(m->frag(w, 31)), N, K, epi, m->stream);
+        return t3k::launch_weight_fragments(w, const_cast<char*>(m->wfrag.as<char>() + (static_cast<const char*>(w) - m->wbuf.as<char>())), N, K, epi, m->stream);
     };
     for (const LayerW& lw : m->layers) {
         HIPCHK(put(lw.wqkv, 3 * d, d, t3k::EPI_ROPE_KV));
@@ -846,7 +866,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
         c.pend_ks = 0;
         {
             t3k::GemmArgs a;
-            a.W = lw.wqkv; a.Wf = m->frag(lw.wqkv, 1); a.A = c.xn; a.M = c.M; a.N = 3 * d; a.K = d;
+            a.W = lw.wqkv; a.Wf = abf ? m->frag(lw.wqkv, 1, c.M) : nullptr; a.A = c.xn; a.M = c.M; a.N = 3 * d; a.K = d;
             a.posmap = c.posmap; a.rowmap = c.rowmap;
             a.rope_cos = m->rope_cos.as<float>(); a.rope_sin = m->rope_sin.as<float>();
             a.q = c.q; a.kcache = kc; a.vcache = vc; a.kv_bf16 = s->kv_bf16 ? 1 : 0; a.n_heads = H; a.max_len = s->max_len;
@@ -864,7 +884,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
         if (tm) tm->mark(K_ATTN);
         {
             t3k::GemmArgs a;
-            a.W = lw.wo; a.Wf = m->frag(lw.wo, 2); a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
+            a.W = lw.wo; a.Wf = abf ? m->frag(lw.wo, 2, c.M) : nullptr; a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
             a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_o;
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
             int ks = 1;
@@ -879,14 +899,14 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
         c.pend_ks = 0;
         {
             t3k::GemmArgs a;
-            a.W = lw.wgu; a.Wf = m->frag(lw.wgu, 4); a.A = c.xn; a.M = c.M; a.N = turbo ? F : 2 * F; a.K = d; a.yact = c.hact;
+            a.W = lw.wgu; a.Wf = abf ? m->frag(lw.wgu, 4, c.M) : nullptr; a.A = c.xn; a.M = c.M; a.N = turbo ? F : 2 * F; a.K = d; a.yact = c.hact;
             a.bias = lw.b_fc;
             HIPCHK(t3k::launch_gemm(a, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, wdt, st));
         }
         if (tm) tm->mark(K_GATEUP);
         {
             t3k::GemmArgs a;
-            a.W = lw.wdown; a.Wf = m->frag(lw.wdown, 8); a.A = c.hact; a.M = c.M; a.N = d; a.K = F;
+            a.W = lw.wdown; a.Wf = abf ? m->frag(lw.wdown, 8, c.M) : nullptr; a.A = c.hact; a.M = c.M; a.N = d; a.K = F;
             a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_down;
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
             int ks = 1;
@@ -929,7 +949,7 @@ int run_head(t3mi_model* m, Session* s, StepTimer* tm) {
                                             s->gpart.as<float>(), s->pend_ks, s->pend_bias));
         s->pend_ks = 0;
         t3k::GemmArgs a;
-        a.W = m->head_w; a.Wf = m->frag(m->head_w, 16); a.A = s->xn.p; a.M = s->rows; a.N = m->V; a.K = d;
+        a.W = m->head_w; a.Wf = m->frag(m->head_w, 16, s->rows); a.A = s->xn.p; a.M = s->rows; a.N = m->V; a.K = d;
         a.y = s->logits.as<float>(); a.ldy = m->V; a.bias = m->head_b;
         HIPCHK(t3k::launch_gemm(a, t3k::EPI_STORE, m->wdtype, m->stream));
         if (tm) tm->mark(K_HEAD);

@@ -1,5 +1,7 @@
 """The activation-stationary bf16 GEMM (batch_kernels.hip, gemm_as_kernel; fragment-major weight copy) against the
-LDS-staged kernels it replaces for batches of up to 128 rows, and against the fp32 path.
+LDS-staged kernels it replaces for batches of up to 1024 rows, and against the fp32 path.  (T3MI_AS=<mask> makes
+exactly the named GEMMs take it at every row count the kernel accepts; without the variable each GEMM has a tuned
+row range, t3mi.cpp frag().)
 
 The two bf16 kernels multiply the same bf16 operands and accumulate in fp32; they differ only in the order of the
 sums (K slices per wave, reduced in LDS).  A sum that differs in its last fp32 bit can flip the bf16 rounding of an
@@ -53,9 +55,9 @@ def _run(model, embs, n, forced=None):
 
 CASES = [
     # (name, turbo, dims, utterances): llama rows = 2 x utterances, Turbo rows = utterances
-    ("llama-tiny", False, synth.TINY, [3, 12, 24, 40, 64]),
-    ("llama-full", False, synth.FULL, [5, 16, 30, 44]),
-    ("turbo-tiny", True, synth.TURBO_TINY, [7, 24, 50, 100]),
+    ("llama-tiny", False, synth.TINY, [3, 12, 24, 40, 64, 100, 260, 500]),
+    ("llama-full", False, synth.FULL, [5, 16, 30, 44, 150]),
+    ("turbo-tiny", True, synth.TURBO_TINY, [7, 24, 50, 100, 300, 1000]),
 ]
 
 
