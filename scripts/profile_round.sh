@@ -16,3 +16,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c3_fetch -o run -- $S --steps 12 --chunk 12 > $OUT/c3_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/c3_write -o run -- $S --steps 12 --chunk 12 > $OUT/c3_write.log 2>&1
 python scripts/pmc_traffic.py $OUT/c3_fetch/run_counter_collection.csv $OUT/c3_write/run_counter_collection.csv | tee $OUT/c3_traffic.json
+# the same session at the cache length the 400-step benchmark averages (S0 258 + 12 steps: L 258..270)
+SL="python3 scripts/run_session.py --utt 64 --s0 258 --dtype bf16"
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c3L_fetch -o run -- $SL --steps 12 --chunk 12 > $OUT/c3L_fetch.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/c3L_write -o run -- $SL --steps 12 --chunk 12 > $OUT/c3L_write.log 2>&1
+python scripts/pmc_traffic.py $OUT/c3L_fetch/run_counter_collection.csv $OUT/c3L_write/run_counter_collection.csv | tee $OUT/c3L_traffic.json
