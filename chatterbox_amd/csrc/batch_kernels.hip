@@ -434,11 +434,12 @@ template <typename KVT> __device__ __forceinline__ float attn_exp(float v) {
     else return expf(v);
 }
 
-template <typename KVT, typename OT>
-__global__ __launch_bounds__(256, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kernel(AttnRowsArgs a) {   // bf16 cache: 4 waves per SIMD (128 VGPRs)
+template <typename KVT, typename OT, int NW>   // NW waves per block
+__global__ __launch_bounds__(64 * NW, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kernel(AttnRowsArgs a) {   // bf16 cache: 4 waves per SIMD (128 VGPRs)
+    constexpr int NS = NW * 8;   // key streams of the block: (wave, key group)
 
-    __shared__ float sm_m[32], sm_l[32];
-    __shared__ __attribute__((aligned(16))) float sm_acc[32][kHeadDim + 4];
+    __shared__ float sm_m[NS], sm_l[NS];
+    __shared__ __attribute__((aligned(16))) float sm_acc[NS][kHeadDim + 4];
     // flat grid: block = qi * H + h (the heads of an item are adjacent, as they are in the cache); a 2-D grid with the
     // items in y is capped at 65535 items, which a prefill of a few hundred prompts exceeds
     const int h = (int)(blockIdx.x % (unsigned)a.n_heads), qi = (int)(blockIdx.x / (unsigned)a.n_heads);
@@ -473,10 +474,10 @@ __global__ __launch_bounds__(256, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kerne
     using Raw = typename KvLoad<KVT>::Raw;
     Raw rka[kAhead], rkb[kAhead], rva[kAhead], rvb[kAhead];
     const int kfirst = wave * 8 + kg;
-    const int trips = (L + 63) / 64;   // block-uniform: streams whose last trip has no key left get masked scores
+    const int trips = (L + 2 * NS - 1) / (2 * NS);   // block-uniform: streams whose last trip has no key left get masked scores
     auto issue = [&](int t, auto SC) {
         constexpr int slot = decltype(SC)::value;
-        const int ka = kfirst + t * 64, kb = ka + 32;
+        const int ka = kfirst + t * (2 * NS), kb = ka + NS;
         const size_t oa = (size_t)(ka < L ? ka : 0) * kHeadDim, ob = (size_t)(kb < L ? kb : 0) * kHeadDim;
         rka[slot] = KvLoad<KVT>::fetch(kp + oa);
         rkb[slot] = KvLoad<KVT>::fetch(kp + ob);
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(256, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kerne
     // arithmetic of trip t on ring slot SC; no branch (an empty stream keeps m = -inf, l = 0, acc = 0)
     auto consume = [&](int t, auto SC) {
         constexpr int slot = decltype(SC)::value;
-        const int ka = kfirst + t * 64, kb = ka + 32;
+        const int ka = kfirst + t * (2 * NS), kb = ka + NS;
         const bool oka = ka < L, okb = kb < L;
         float kva[8], kvb[8], vva[8], vvb[8];
         KvLoad<KVT>::unpack(rka[slot], kva);
@@ -545,7 +546,9 @@ __global__ __launch_bounds__(256, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kerne
         consume(t + 2, S2); T3K_SB(); issue(t + kAhead + 2, S2); T3K_SB();
     }
 #undef T3K_SB
-    // merge the 32 streams (4 waves x 8 key groups): stream id = wave*8 + kg
+    // (NW = 1: merging the 8 streams of the one wave in registers -- a shuffle butterfly over lane bits 3..5 instead of LDS +
+    // barrier -- measured slower: 1.828 vs 1.802 ms per step at 64 utterances; every lane then pays the exponentials.)
+    // merge the NS streams (NW waves x 8 key groups): stream id = wave*8 + kg
     const int sid = wave * 8 + kg;
     if (dc == 0) { sm_m[sid] = m_run; sm_l[sid] = l_run; }
 #pragma unroll
@@ -554,10 +557,10 @@ __global__ __launch_bounds__(256, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kerne
     if (tid < kHeadDim) {
         float M = -INFINITY;
 #pragma unroll
-        for (int s2 = 0; s2 < 32; ++s2) M = fmaxf(M, sm_m[s2]);
+        for (int s2 = 0; s2 < NS; ++s2) M = fmaxf(M, sm_m[s2]);
         float den = 0.f, o = 0.f;
 #pragma unroll
-        for (int s2 = 0; s2 < 32; ++s2) {
+        for (int s2 = 0; s2 < NS; ++s2) {
             const float ms = sm_m[s2];
             const float ws = ms > -INFINITY ? expf(ms - M) : 0.f;
             den = fmaf(ws, sm_l[s2], den);
@@ -1594,11 +1597,37 @@ hipError_t launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
     if (!a.q || !a.kcache || !a.vcache || !a.posmap || !a.out || a.M <= 0 || a.n_heads <= 0 || a.max_len <= 0)
         return hipErrorInvalidValue;
     if ((long long)a.M * a.n_heads > 0x7FFFFFFFLL) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)a.M * (unsigned)a.n_heads), block(256);
-    if (a.kv_bf16 && a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, uint16_t>), grid, block, 0, s, a);
-    else if (a.kv_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, float>), grid, block, 0, s, a);
-    else if (a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<float, uint16_t>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn_rows_kernel<float, float>), grid, block, 0, s, a);
+    const dim3 grid((unsigned)a.M * (unsigned)a.n_heads);
+    // Waves per (item, head) block by the number of such blocks: 1 from 512 blocks, 2 from 256, else 4.  With one wave per
+    // block all 2048 blocks of a 128-row step are resident at once (8 per CU) and start and end at different times; with
+    // 4-wave blocks they ran as two rounds in lockstep, and HBM idled through both rounds' prologues and merges.
+    // Measured, 400-step bf16 sessions, ms per step with 4 / 2 / 1 waves: 64 utterances (2048 blocks) 1.852 / 1.807 /
+    // 1.802; 16 utterances (512) 1.114 / 1.090 / 1.070; 512 utterances 7.909 / 7.851 / 7.827; 4 utterances (128 blocks)
+    // 0.943 / 0.940 / 0.979; Turbo 16 x L 407..707 (256 blocks) 0.877 / 0.864 / 0.933; Turbo 8 (128) 0.823 / 0.840 / 0.919;
+    // fp32 cache, 64 utterances 4.279 / 4.374 / 4.110.
+    const long long blocks = (long long)a.M * a.n_heads;
+    const int nw = blocks >= 512 ? 1 : (blocks >= 256 ? 2 : 4);
+    if (nw == 1) {
+        const dim3 block(64);
+        if (a.kv_bf16 && a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, uint16_t, 1>), grid, block, 0, s, a);
+        else if (a.kv_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, float, 1>), grid, block, 0, s, a);
+        else if (a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<float, uint16_t, 1>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((attn_rows_kernel<float, float, 1>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
+    if (nw == 2) {
+        const dim3 block(128);
+        if (a.kv_bf16 && a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, uint16_t, 2>), grid, block, 0, s, a);
+        else if (a.kv_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, float, 2>), grid, block, 0, s, a);
+        else if (a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<float, uint16_t, 2>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((attn_rows_kernel<float, float, 2>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
+    const dim3 block(256);
+    if (a.kv_bf16 && a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, uint16_t, 4>), grid, block, 0, s, a);
+    else if (a.kv_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, float, 4>), grid, block, 0, s, a);
+    else if (a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<float, uint16_t, 4>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_rows_kernel<float, float, 4>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
