@@ -1063,29 +1063,36 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a, int tiles32,
 // utterances 1.147 -> 0.980.  Two things the first version got wrong, both visible only in the ISA: a run-time
 // `if (tile < live tiles)` around the MFMAs made every LDS read wait on its own (loop 8.3 us instead of 2.4), and a
 // staging array of HIP's uint4 STRUCT stayed in scratch memory (copied with memcpy; the native vector type does not).
-template <int EPI>
-__global__ __launch_bounds__(64) void fragment_weights_kernel(const uint16_t* __restrict__ W, uint16_t* __restrict__ out, int N, int K) {
-    const int ksteps = K >> 5;
-    const int q = blockIdx.x / ksteps, j = blockIdx.x % ksteps;   // sub-tile, 32-k step
+// fp32 operands (T = float) take the same kernel in the same byte shapes: a "k-step" is 64 bytes of a row for both types
+// (32 bf16 or 16 fp32 k; one v_mfma_f32_16x16x32_bf16, or four v_mfma_f32_16x16x4_f32 -- lane (n, g) holds k = 16 j + 4 g
+// + i for MFMA i, exact fp32 products), a phase is 8 steps (512 B of every row), a fragment is 1 KB.
+template <int EPI, typename T>
+__global__ __launch_bounds__(64) void fragment_weights_kernel(const T* __restrict__ W, T* __restrict__ out, int N, int K) {
+    constexpr int E = 16 / (int)sizeof(T), KS = 4 * E;   // elements per 16 B; k per step
+    const int ksteps = K / KS;
+    const int q = blockIdx.x / ksteps, j = blockIdx.x % ksteps;   // sub-tile, k-step
     const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
     const int f = tile32_feature<EPI>(q >> 1, ((q & 1) << 4) + n, N);
     uint4 v{0u, 0u, 0u, 0u};
-    if (f < N) v = *reinterpret_cast<const uint4*>(W + (size_t)f * K + 32 * j + 8 * g);
+    if (f < N) v = *reinterpret_cast<const uint4*>(W + (size_t)f * K + KS * j + E * g);
     reinterpret_cast<uint4*>(out)[(size_t)blockIdx.x * 64 + lane] = v;
 }
 
 constexpr int kAsRedStride = 20;   // floats per (row) of the reduction buffer: the 4 lane groups of a store hit 4 x 16 distinct banks
 
-template <int EPI, int NSUB, int KB, int MC>
+template <int EPI, typename T, int NSUB, int KB, int MC>
 __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
-    using T = uint16_t;
+    constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte piece: 8 (bf16) or 4 (fp32)
+    constexpr int KS = 4 * E;                // k per step (64 B of a row): 32 or 16
+    constexpr int PHK = 8 * KS;              // k per staging phase (512 B of every row): 256 or 128
     constexpr int KW = 8 / NSUB;             // K slices: waves per sub-tile
-    constexpr int NPH = KB / 256;            // staging phases of 256 k (512 B of every row)
-    constexpr int JQ = 8 / KW;               // MFMA k-steps per wave and phase (a phase is 8 steps of 32 k)
-    constexpr int JW = NPH * JQ;             // MFMA k-steps per wave
+    constexpr int NPH = KB / PHK;            // staging phases
+    constexpr int JQ = 8 / KW;               // k-steps per wave and phase
+    constexpr int JW = NPH * JQ;             // k-steps (weight fragments) per wave
     constexpr int NT = MC / 16;              // accumulator tiles per wave = staging pieces per thread and phase
-    constexpr int LDA = KB + 8;              // LDS row stride in elements (+16 B: 16-row fragment reads fall in distinct banks)
+    constexpr int LDA = KB + E;              // LDS row stride in elements (+16 B: 16-row fragment reads fall in distinct banks)
     constexpr int RS = kAsRedStride;
+    static_assert(NPH >= 2 && NPH <= 8, "2 to 8 staging phases");
     extern __shared__ __attribute__((aligned(16))) unsigned char as_raw[];
     T* lds = reinterpret_cast<T*>(as_raw);   // [MC][LDA], later float red[KW][NSUB][MC][RS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1097,31 +1104,31 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
                                   ? a.dbg + 4 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
     if (dbg) dbg[0] = wall_clock64();
     // Every global load of the kernel is issued here, activations first: they come from L2 and are consumed first, and
-    // loads complete in order.  Phase q of the activation rows = k 256 q .. 256 q + 255 of the block's range: 32 pieces of
-    // 16 B per row, piece tid + 512 i -> row (tid + 512 i) / 32 (32 consecutive threads fetch one 512-byte run).
+    // loads complete in order.  Phase q of the activation rows = k PHK q .. PHK q + PHK - 1 of the block's range: 32 pieces
+    // of 16 B per row, piece tid + 512 i -> row (tid + 512 i) / 32 (32 consecutive threads fetch one 512-byte run).
     u32x4 va[NPH * NT];
     {
-        const T* Ap = static_cast<const T*>(a.A) + (size_t)kz * KB + (tid & 31) * 8;
+        const T* Ap = static_cast<const T*>(a.A) + (size_t)kz * KB + (tid & 31) * E;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             int row = m0 + ((tid + 512 * i) >> 5);
             row = row < a.M ? row : a.M - 1;
             const T* rp = Ap + (size_t)row * K;
 #pragma unroll
-            for (int q = 0; q < NPH; ++q) va[q * NT + i] = *reinterpret_cast<const u32x4*>(rp + q * 256);
+            for (int q = 0; q < NPH; ++q) va[q * NT + i] = *reinterpret_cast<const u32x4*>(rp + q * PHK);
         }
     }
     // this wave's weight fragments: sub-tile qs, k-steps 8 q + JQ kw + jj of the block's range (1 KB each, contiguous per wave)
     int qs = blockIdx.x * NSUB + sub;
     qs = qs < 2 * tiles32 ? qs : 2 * tiles32 - 1;
-    const u32x4* wp = reinterpret_cast<const u32x4*>(a.Wf) + ((size_t)qs * (K >> 5) + (size_t)kz * (KB / 32) + kw * JQ) * 64 + lane;
+    const u32x4* wp = reinterpret_cast<const u32x4*>(a.Wf) + ((size_t)qs * (K / KS) + (size_t)kz * (KB / KS) + kw * JQ) * 64 + lane;
     u32x4 wf[JW];
 #pragma unroll
     for (int q = 0; q < NPH; ++q)
 #pragma unroll
         for (int jj = 0; jj < JQ; ++jj) wf[q * JQ + jj] = wp[(size_t)(q * 8 + jj) * 64];
     __builtin_amdgcn_sched_barrier(0);   // keep the loads above the stores below (the compiler otherwise sinks the weight loads)
-    T* sdst = lds + (tid >> 5) * LDA + (tid & 31) * 8;
+    T* sdst = lds + (tid >> 5) * LDA + (tid & 31) * E;
 #pragma unroll
     for (int i = 0; i < NT; ++i) *reinterpret_cast<u32x4*>(sdst + i * 16 * LDA) = va[i];
     __syncthreads();
@@ -1131,32 +1138,46 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const T* ab = lds + nl * LDA + (kw * JQ) * 32 + g * 8;   // lane (nl, g), phase q, step jj: k = 256 q + 32 (JQ kw + jj) + 8 g .. + 7
+    const T* ab = lds + nl * LDA + (kw * JQ) * KS + g * E;   // lane (nl, g), phase q, step jj: k = PHK q + KS (JQ kw + jj) + E g .. + E - 1
     // (the phase index comes as a type: with a loop variable the staging registers' indices are not constants when the
     // compiler decides where `va` lives, and it keeps the array in scratch memory)
     auto phase = [&](auto QC) {
         constexpr int q = decltype(QC)::value;
-        if constexpr (q + 1 < NPH) {   // phase q + 1 -> LDS while phase q is multiplied
+        if constexpr (q < NPH) {
+            if constexpr (q + 1 < NPH) {   // phase q + 1 -> LDS while phase q is multiplied
 #pragma unroll
-            for (int i = 0; i < NT; ++i) *reinterpret_cast<u32x4*>(sdst + i * 16 * LDA + (q + 1) * 256) = va[(q + 1) * NT + i];
-        }
-#pragma unroll
-        for (int jj = 0; jj < JQ; ++jj) {
-            const bf16x8 bfr = __builtin_bit_cast(bf16x8, wf[q * JQ + jj]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8*>(ab + t * 16 * LDA + q * 256 + jj * 32);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[t], 0, 0, 0);
+                for (int i = 0; i < NT; ++i) *reinterpret_cast<u32x4*>(sdst + i * 16 * LDA + (q + 1) * PHK) = va[(q + 1) * NT + i];
             }
+#pragma unroll
+            for (int jj = 0; jj < JQ; ++jj) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const T* ap = ab + t * 16 * LDA + q * PHK + jj * KS;
+                    if constexpr (sizeof(T) == 2) {
+                        const bf16x8 bfr = __builtin_bit_cast(bf16x8, wf[q * JQ + jj]);
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[t], 0, 0, 0);
+                    } else {
+                        const f32x4 bfr = __builtin_bit_cast(f32x4, wf[q * JQ + jj]);
+                        const f32x4 af = *reinterpret_cast<const f32x4*>(ap);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bfr.x, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bfr.y, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bfr.z, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bfr.w, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();   // phase q + 1 is visible; after the last phase: every wave is done with the activation rows
         }
-        __syncthreads();   // phase q + 1 is visible; after the last phase: every wave is done with the activation rows
     };
     phase(std::integral_constant<int, 0>{});
     phase(std::integral_constant<int, 1>{});
-    if constexpr (NPH == 4) {
-        phase(std::integral_constant<int, 2>{});
-        phase(std::integral_constant<int, 3>{});
-    }
+    phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{});
+    phase(std::integral_constant<int, 4>{});
+    phase(std::integral_constant<int, 5>{});
+    phase(std::integral_constant<int, 6>{});
+    phase(std::integral_constant<int, 7>{});
     if (dbg) dbg[2] = wall_clock64();
     float* red = reinterpret_cast<float*>(as_raw);   // the buffer becomes the reduction area
     {
@@ -1313,22 +1334,22 @@ inline int tiles32_of(int N) {
     return (N + 31) / 32;
 }
 
-template <int EPI, int NSUB, int KB, int MC>
+template <int EPI, typename T, int NSUB, int KB, int MC>
 hipError_t launch_gemm_as_v(const GemmArgs& a, int tiles32, int gz, hipStream_t s) {
-    constexpr int lds_a = MC * (KB + 8) * 2, lds_r = 8 * MC * kAsRedStride * 4;
-    constexpr int lds = lds_a > lds_r ? lds_a : lds_r;   // 132,096 B at KB = 1024, MC = 64
+    constexpr int lds_a = MC * (KB * (int)sizeof(T) + 16), lds_r = 8 * MC * kAsRedStride * 4;
+    constexpr int lds = lds_a > lds_r ? lds_a : lds_r;   // bf16: 66,048 B at KB = 1024, MC = 32
     static bool attr_done[64] = {};   // one flag per instantiation and device
     int dev = 0;
     hipError_t ed = hipGetDevice(&dev);
     if (ed != hipSuccess) return ed;
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_as_kernel<EPI, NSUB, KB, MC>),
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_as_kernel<EPI, T, NSUB, KB, MC>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e0 != hipSuccess) return e0;
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const dim3 grid((2 * tiles32 + NSUB - 1) / NSUB, (a.M + MC - 1) / MC, gz);
-    hipLaunchKernelGGL((gemm_as_kernel<EPI, NSUB, KB, MC>), grid, dim3(512), lds, s, a, tiles32);
+    hipLaunchKernelGGL((gemm_as_kernel<EPI, T, NSUB, KB, MC>), grid, dim3(512), lds, s, a, tiles32);
     return hipGetLastError();
 }
 
@@ -1339,25 +1360,27 @@ constexpr int kAsMinBlocks = 192;   // sub-tiles per block and K range per block
 // 1.456 / 1.354 / 1.386, 48 rows 1.353 / 1.263 / 1.298, 32 rows 1.236 / 1.136 / 1.112, 16 rows 1.118 / 1.017 / 0.981:
 // smaller chunks put more blocks in flight (two 66 KB blocks fit a CU) and shorten the staging each block waits for;
 // the weights are re-requested once per chunk, but from L2.  (kAsMinBlocks 128 / 192 / 320 / 512: 192 is best or tied at
-// every batch size.)
+// every batch size.)  fp32 operands, the same rule (64 utterances, 200 steps: 32-row chunks 3.454 ms per step, 16-row chunks
+// 3.807, the LDS-staged kernel 3.603).
+template <typename T>
 inline int as_chunk_rows(int M) { return M <= 32 ? 16 : 32; }
 
-template <int EPI, int NSUB, int KB>
+template <int EPI, typename T, int NSUB, int KB>
 hipError_t launch_gemm_as_m(const GemmArgs& a, int tiles32, int gz, hipStream_t s) {
-    if (as_chunk_rows(a.M) == 16) return launch_gemm_as_v<EPI, NSUB, KB, 16>(a, tiles32, gz, s);
-    return launch_gemm_as_v<EPI, NSUB, KB, 32>(a, tiles32, gz, s);
+    if (as_chunk_rows<T>(a.M) == 16) return launch_gemm_as_v<EPI, T, NSUB, KB, 16>(a, tiles32, gz, s);
+    return launch_gemm_as_v<EPI, T, NSUB, KB, 32>(a, tiles32, gz, s);
 }
 
 // Activation-stationary launch, or `handled = false` when the shape is not its own (the caller falls through).
-template <int EPI>
+template <int EPI, typename T>
 hipError_t launch_gemm_as(const GemmArgs& a, hipStream_t s, bool& handled) {
     handled = false;
     const bool splittable = (EPI == EPI_RESID || EPI == EPI_STORE) && a.part != nullptr;
     if (EPI == EPI_SWIGLU && a.N % 32) return hipSuccess;
-    const int mc = as_chunk_rows(a.M);
+    const int mc = as_chunk_rows<T>(a.M);
     const int tiles32 = tiles32_of<EPI>(a.N), chunks = (a.M + mc - 1) / mc;
     // the block's K range: all of K (1024 or 512), or for the residual GEMMs a split into fp32 partial slabs -- 1024 k
-    // each, 512 when that leaves fewer than 192 blocks
+    // each, 512 when that leaves fewer than kAsMinBlocks blocks
     int KB = 0;
     if (a.K == 1024 || a.K == 512) KB = a.K;
     else if (splittable && a.K % 1024 == 0) {
@@ -1370,14 +1393,27 @@ hipError_t launch_gemm_as(const GemmArgs& a, hipStream_t s, bool& handled) {
     const bool four = (long long)((2 * tiles32 + 3) / 4) * chunks * gz >= kAsMinBlocks;
     handled = true;
     hipError_t e;
-    if (KB == 1024) e = four ? launch_gemm_as_m<EPI, 4, 1024>(a, tiles32, gz, s) : launch_gemm_as_m<EPI, 2, 1024>(a, tiles32, gz, s);
-    else e = four ? launch_gemm_as_m<EPI, 4, 512>(a, tiles32, gz, s) : launch_gemm_as_m<EPI, 2, 512>(a, tiles32, gz, s);
+    if (KB == 1024) e = four ? launch_gemm_as_m<EPI, T, 4, 1024>(a, tiles32, gz, s) : launch_gemm_as_m<EPI, T, 2, 1024>(a, tiles32, gz, s);
+    else e = four ? launch_gemm_as_m<EPI, T, 4, 512>(a, tiles32, gz, s) : launch_gemm_as_m<EPI, T, 2, 512>(a, tiles32, gz, s);
     if (a.ks_out != nullptr) *a.ks_out = gz;
     if (e != hipSuccess || gz == 1) return e;
     if (a.ks_out != nullptr && EPI == EPI_RESID && a.resid == a.y) return e;   // the caller folds (fused into its norm launch)
     hipLaunchKernelGGL(fold_partials_kernel, dim3(a.M, (a.N + 255) / 256), dim3(256), 0, s, a.y, EPI == EPI_RESID ? a.resid : nullptr, a.part, gz,
                        a.bias, a.M, a.N, a.ldy);
     return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_gemm_as_e(const GemmArgs& a, int epilogue, hipStream_t s, bool& handled) {
+    switch (epilogue) {
+        case EPI_STORE: return launch_gemm_as<EPI_STORE, T>(a, s, handled);
+        case EPI_RESID: return launch_gemm_as<EPI_RESID, T>(a, s, handled);
+        case EPI_GELU: return launch_gemm_as<EPI_GELU, T>(a, s, handled);
+        case EPI_SWIGLU: return launch_gemm_as<EPI_SWIGLU, T>(a, s, handled);
+        case EPI_ROPE_KV: return launch_gemm_as<EPI_ROPE_KV, T>(a, s, handled);
+    }
+    handled = false;
+    return hipErrorInvalidValue;
 }
 
 template <int EPI, int MT, int NT>
@@ -1495,16 +1531,9 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
     // 16x slower than the bf16 one, so with few rows (one live wave per block) the first generation's 16-feature tiles
     // with K split over the waves win (8 rows, Turbo batched: 5156 vs 3516 tok/s)
     // 256 rows or more of bf16 operands: the register-blocked kernel (gemm_wide_kernel) where it leaves enough blocks
-    if (wdtype == 1 && a.Wf != nullptr && a.M <= kAsMaxRows) {
+    if ((wdtype == 1 || wdtype == 0) && a.Wf != nullptr && a.M <= kAsMaxRows) {
         bool handled = false;
-        hipError_t e = hipSuccess;
-        switch (epilogue) {
-            case EPI_STORE: e = launch_gemm_as<EPI_STORE>(a, s, handled); break;
-            case EPI_RESID: e = launch_gemm_as<EPI_RESID>(a, s, handled); break;
-            case EPI_GELU: e = launch_gemm_as<EPI_GELU>(a, s, handled); break;
-            case EPI_SWIGLU: e = launch_gemm_as<EPI_SWIGLU>(a, s, handled); break;
-            case EPI_ROPE_KV: e = launch_gemm_as<EPI_ROPE_KV>(a, s, handled); break;
-        }
+        const hipError_t e = wdtype == 1 ? launch_gemm_as_e<uint16_t>(a, epilogue, s, handled) : launch_gemm_as_e<float>(a, epilogue, s, handled);
         if (handled || e != hipSuccess) return e;
     }
     constexpr int wide_min = 256;
@@ -1546,21 +1575,28 @@ size_t weight_fragment_elems(int N, int K, int epilogue) {
     return (size_t)t * 32 * K;
 }
 
-hipError_t launch_weight_fragments(const void* W, void* out, int N, int K, int epilogue, hipStream_t s) {
-    if (!W || !out || N <= 0 || K <= 0 || (K & 31)) return hipErrorInvalidValue;
-    if (epilogue == EPI_ROPE_KV && N % kHeadDim) return hipErrorInvalidValue;
-    if (epilogue == EPI_SWIGLU && (N % 32)) return hipErrorInvalidValue;
-    const uint16_t* w = static_cast<const uint16_t*>(W);
-    uint16_t* o = static_cast<uint16_t*>(out);
-    const size_t blocks = weight_fragment_elems(N, K, epilogue) / 512;   // one per (sub-tile, 32-k step)
+namespace {
+template <typename T>
+hipError_t launch_weight_fragments_t(const T* w, T* o, int N, int K, int epilogue, hipStream_t s) {
+    constexpr int frag_elems = 16 * 4 * (16 / (int)sizeof(T));   // 16 features x one 64-byte step
+    const size_t blocks = weight_fragment_elems(N, K, epilogue) / frag_elems;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks), block(64);
     switch (epilogue) {
-        case EPI_ROPE_KV: hipLaunchKernelGGL(fragment_weights_kernel<EPI_ROPE_KV>, grid, block, 0, s, w, o, N, K); break;
-        case EPI_SWIGLU: hipLaunchKernelGGL(fragment_weights_kernel<EPI_SWIGLU>, grid, block, 0, s, w, o, N, K); break;
-        default: hipLaunchKernelGGL(fragment_weights_kernel<EPI_STORE>, grid, block, 0, s, w, o, N, K); break;
+        case EPI_ROPE_KV: hipLaunchKernelGGL((fragment_weights_kernel<EPI_ROPE_KV, T>), grid, block, 0, s, w, o, N, K); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((fragment_weights_kernel<EPI_SWIGLU, T>), grid, block, 0, s, w, o, N, K); break;
+        default: hipLaunchKernelGGL((fragment_weights_kernel<EPI_STORE, T>), grid, block, 0, s, w, o, N, K); break;
     }
     return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_weight_fragments(const void* W, void* out, int N, int K, int epilogue, int wdtype, hipStream_t s) {
+    if (!W || !out || N <= 0 || K <= 0 || (K & 31) || (wdtype != 0 && wdtype != 1)) return hipErrorInvalidValue;
+    if (epilogue == EPI_ROPE_KV && N % kHeadDim) return hipErrorInvalidValue;
+    if (epilogue == EPI_SWIGLU && (N % 32)) return hipErrorInvalidValue;
+    if (wdtype == 1) return launch_weight_fragments_t<uint16_t>(static_cast<const uint16_t*>(W), static_cast<uint16_t*>(out), N, K, epilogue, s);
+    return launch_weight_fragments_t<float>(static_cast<const float*>(W), static_cast<float*>(out), N, K, epilogue, s);
 }
 
 hipError_t launch_rmsnorm_rows(float* x, const float* w, float eps, void* out, int M, int d, int act_bf16, hipStream_t s,

@@ -76,7 +76,7 @@ struct AttnArgs {
 // many-row regime (batched decode, prefill): skinny GEMM on the matrix cores, see batch_kernels.hip
 struct GemmArgs {
     const void* W = nullptr;      // [N, K] row-major, fp32 or bf16
-    const void* Wf = nullptr;     // bf16 only: the same matrix fragment-major (launch_weight_fragments with this launch's epilogue), or nullptr
+    const void* Wf = nullptr;     // the same matrix fragment-major (launch_weight_fragments with this launch's epilogue and type), or nullptr
     const void* A = nullptr;      // [M, K] activation rows: float (fp32 weights) or bf16 (bf16 weights)
     int M = 0, N = 0, K = 0;
     float* y = nullptr;           // EPI_STORE / EPI_RESID output [M, ldy] fp32
@@ -157,12 +157,12 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t s);
 hipError_t launch_prefill_embed(const EmbedArgs& a, hipStream_t s);
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t s);
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t s);
-// Fragment-major copy of a bf16 matrix W [N, K] for the activation-stationary GEMM (<= kAsMaxRows rows; GemmArgs::Wf):
-// per 16-feature sub-tile (in the partner order of `epilogue`) and 32-k step, the 64 x 16 B of one MFMA operand.
-// weight_fragment_elems = bf16 elements of the copy (N rounded up to whole 32-feature tiles).
+// Fragment-major copy of a matrix W [N, K] (wdtype 0 fp32 / 1 bf16) for the activation-stationary GEMM (<= kAsMaxRows
+// rows; GemmArgs::Wf): per 16-feature sub-tile (in the partner order of `epilogue`) and 64-byte k-step, the 64 x 16 B of
+// one MFMA operand.  weight_fragment_elems = elements of the copy (N rounded up to whole 32-feature tiles).
 constexpr int kAsMaxRows = 1024;
 size_t weight_fragment_elems(int N, int K, int epilogue);
-hipError_t launch_weight_fragments(const void* W, void* out, int N, int K, int epilogue, hipStream_t s);
+hipError_t launch_weight_fragments(const void* W, void* out, int N, int K, int epilogue, int wdtype, hipStream_t s);
 // row norms of the many-row path; with ks > 0 they first complete x from the K-split partial slabs of the residual
 // GEMM before them: x[m] += pbias + sum_s part[s][m] (written back)
 hipError_t launch_layernorm_rows(float* x, const float* w, const float* b, float eps, void* out, int M, int d, int act_bf16,

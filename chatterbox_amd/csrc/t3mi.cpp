@@ -143,20 +143,31 @@ struct t3mi_model {
     int as_mask = 15;                  // which GEMMs may take it: 1 qkv, 2 o_proj, 4 gate_up / c_fc, 8 down, 16 head
     bool as_forced = false;            // T3MI_AS=<mask> set: exactly the named GEMMs take it at every row count the kernel accepts (tests, A/B runs)
     // The fragment-major twin of a matrix in wbuf for a launch of M rows, or nullptr (the LDS-staged kernels then run).
-    // Row ranges per GEMM, measured over 400-step bf16 sessions (profiles/r02_gemm_as_ab.txt): qkv wins up to 1024 rows,
-    // gate_up up to 512, down up to 384 (at 512 it loses 0.1 ms per step), o_proj from 96 rows (below, its K-split
-    // LDS-staged form is 1 % ahead) to 512; the head only when T3MI_AS names it (no faster at any size).
+    // Row ranges per GEMM, measured over 400-step sessions (profiles/r02_gemm_as_ab.txt).  bf16: qkv wins up to 1024
+    // rows, gate_up up to 512, down up to 384 (at 512 it loses 0.1 ms per step), o_proj from 96 rows (below, its K-split
+    // LDS-staged form is 1 % ahead); the head only when T3MI_AS names it (no faster at any size).  fp32 (exact-fp32
+    // MFMA, 16x the matrix-core time per product): qkv up to 1024 rows, gate_up up to 96, down up to 128, o_proj never.
     const void* frag(const void* w, int which, int M) const {
         if (!wfrag.p || !(as_mask & which)) return nullptr;
         int lo = 1, hi = 0;
         if (as_forced) which = 0;   // no tuned range: the kernel's own limit
-        switch (which) {
-            case 1: hi = 1024; break;
-            case 2: lo = 96; hi = 512; break;
-            case 4: hi = 512; break;
-            case 8: hi = 384; break;
-            case 16: hi = 128; break;
-            default: hi = t3k::kAsMaxRows; break;
+        if (wdtype == T3MI_W_BF16) {
+            switch (which) {
+                case 1: hi = 1024; break;
+                case 2: lo = 96; hi = 1024; break;
+                case 4: hi = 512; break;
+                case 8: hi = 384; break;
+                case 16: hi = 0; break;
+                default: hi = t3k::kAsMaxRows; break;
+            }
+        } else {
+            switch (which) {
+                case 1: hi = 1024; break;
+                case 4: hi = 96; break;
+                case 8: hi = 128; break;
+                case 2: case 16: hi = 0; break;
+                default: hi = t3k::kAsMaxRows; break;
+            }
         }
         if (M < lo || M > hi) return nullptr;
         return static_cast<const char*>(wfrag.p) + (static_cast<const char*>(w) - static_cast<const char*>(wbuf.p));
@@ -677,7 +688,6 @@ int load_turbo(t3mi_model* m, const t3mi::SafeTensorsFile& st, const char* cache
 // on the device in about a millisecond.  T3MI_AS=<mask> picks the GEMMs that use it (t3mi_model::as_mask; 0 = none, the LDS-staged kernels then serve those
 // batches; the head is not in the default: measured no faster there).
 int build_fragments(t3mi_model* m) {
-    if (m->wdtype != T3MI_W_BF16) return T3MI_OK;
     if (const char* e = std::getenv("T3MI_AS")) {
         m->as_mask = std::atoi(e) & 31;
         m->as_forced = true;
@@ -686,14 +696,16 @@ int build_fragments(t3mi_model* m) {
     const int d = m->d, F = m->F, V = m->V;
     const bool turbo = m->variant == T3MI_VARIANT_TURBO;
     if (d % 32 || F % 32) return T3MI_OK;
+    const size_t es = m->wdtype == T3MI_W_BF16 ? 2 : 4;
     // every per-layer matrix has a whole number of 32-feature tiles, so its fragment image has its size; the head (last
     // in wbuf) is rounded up to one
     const size_t head_off = static_cast<const char*>(m->head_w) - m->wbuf.as<char>();
-    const size_t need = head_off + t3k::weight_fragment_elems(V, d, t3k::EPI_STORE) * 2;
+    const size_t need = head_off + t3k::weight_fragment_elems(V, d, t3k::EPI_STORE) * es;
     HIPCHK(hipDeviceSynchronize());   // the uploads and conversions into wbuf
     HIPCHK(m->wfrag.alloc(need));
+    const int wdt = m->wdtype == T3MI_W_BF16 ? 1 : 0;
     auto put = [&](const void* w, int N, int K, int epi) -> hipError_t {
-        return t3k::launch_weight_fragments(w, const_cast<char*>(m->wfrag.as<char>() + (static_cast<const char*>(w) - m->wbuf.as<char>())), N, K, epi, m->stream);
+        return t3k::launch_weight_fragments(w, m->wfrag.as<char>() + (static_cast<const char*>(w) - m->wbuf.as<char>()), N, K, epi, wdt, m->stream);
     };
     for (const LayerW& lw : m->layers) {
         HIPCHK(put(lw.wqkv, 3 * d, d, t3k::EPI_ROPE_KV));
@@ -854,6 +866,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
     const int abf = (m->wdtype == T3MI_W_BF16 && !c.act_f32) ? 1 : 0;
     const int wdt = (m->wdtype == T3MI_W_BF16 && c.act_f32) ? 2 : m->wdtype;   // launch_gemm's operand-type selector
     const bool turbo = m->variant == T3MI_VARIANT_TURBO;
+    const bool as_ok = wdt == m->wdtype;   // not the mixed form (bf16 weights x fp32 activation rows): the fragment image serves one operand type
     const size_t layer_kv = (size_t)s->rows * H * s->max_len * 64 * (s->kv_bf16 ? 2 : 4);   // bytes
     hipStream_t st = m->stream;
     for (int l = 0; l < m->n_layers; ++l) {
@@ -866,7 +879,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
         c.pend_ks = 0;
         {
             t3k::GemmArgs a;
-            a.W = lw.wqkv; a.Wf = abf ? m->frag(lw.wqkv, 1, c.M) : nullptr; a.A = c.xn; a.M = c.M; a.N = 3 * d; a.K = d;
+            a.W = lw.wqkv; a.Wf = as_ok ? m->frag(lw.wqkv, 1, c.M) : nullptr; a.A = c.xn; a.M = c.M; a.N = 3 * d; a.K = d;
             a.posmap = c.posmap; a.rowmap = c.rowmap;
             a.rope_cos = m->rope_cos.as<float>(); a.rope_sin = m->rope_sin.as<float>();
             a.q = c.q; a.kcache = kc; a.vcache = vc; a.kv_bf16 = s->kv_bf16 ? 1 : 0; a.n_heads = H; a.max_len = s->max_len;
@@ -884,7 +897,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
         if (tm) tm->mark(K_ATTN);
         {
             t3k::GemmArgs a;
-            a.W = lw.wo; a.Wf = abf ? m->frag(lw.wo, 2, c.M) : nullptr; a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
+            a.W = lw.wo; a.Wf = as_ok ? m->frag(lw.wo, 2, c.M) : nullptr; a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
             a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_o;
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
             int ks = 1;
@@ -899,14 +912,14 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
         c.pend_ks = 0;
         {
             t3k::GemmArgs a;
-            a.W = lw.wgu; a.Wf = abf ? m->frag(lw.wgu, 4, c.M) : nullptr; a.A = c.xn; a.M = c.M; a.N = turbo ? F : 2 * F; a.K = d; a.yact = c.hact;
+            a.W = lw.wgu; a.Wf = as_ok ? m->frag(lw.wgu, 4, c.M) : nullptr; a.A = c.xn; a.M = c.M; a.N = turbo ? F : 2 * F; a.K = d; a.yact = c.hact;
             a.bias = lw.b_fc;
             HIPCHK(t3k::launch_gemm(a, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, wdt, st));
         }
         if (tm) tm->mark(K_GATEUP);
         {
             t3k::GemmArgs a;
-            a.W = lw.wdown; a.Wf = abf ? m->frag(lw.wdown, 8, c.M) : nullptr; a.A = c.hact; a.M = c.M; a.N = d; a.K = F;
+            a.W = lw.wdown; a.Wf = as_ok ? m->frag(lw.wdown, 8, c.M) : nullptr; a.A = c.hact; a.M = c.M; a.N = d; a.K = F;
             a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_down;
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
             int ks = 1;

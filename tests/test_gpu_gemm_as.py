@@ -88,6 +88,38 @@ def test_activation_stationary_gemm_equals_staged_gemm(name, turbo, dims, utts):
             m.close()
 
 
+F32_AS_VS_STAGED_TOL = 1e-4   # exact fp32 products on both sides, sums in another order (observed ~1e-6)
+
+
+@pytest.mark.parametrize("name,turbo,dims,utts", [("llama-tiny", False, synth.TINY, [3, 12, 24, 40, 100, 300]),
+                                                   ("llama-full", False, synth.FULL, [5, 30]),
+                                                   ("turbo-tiny", True, synth.TURBO_TINY, [7, 50, 300])],
+                         ids=["llama-tiny", "llama-full", "turbo-tiny"])
+def test_fp32_activation_stationary_gemm_equals_staged_gemm(name, turbo, dims, utts):
+    """fp32 operands through the same kernel (four v_mfma_f32_16x16x4_f32 per 64-byte step, exact fp32 products): every
+    GEMM forced onto it, and the default row ranges, against the LDS-staged fp32 kernels; greedy tokens of the default
+    dispatch equal the staged kernels' wherever the top two logits are not within the tolerance of each other."""
+    path = synth.ensure_turbo_checkpoint(dims, 4321) if turbo else synth.ensure_checkpoint(dims, 1234)
+    n = 3
+    rpu = 1 if turbo else 2
+    staged = _open(path, turbo, 0, dims, dtype="f32")
+    as_all = _open(path, turbo, 31, dims, dtype="f32")
+    as_dflt = (cb.load_t3_turbo if turbo else cb.load_t3)(path, device=0, dtype="f32", start_speech_token=dims.start_speech_token,
+                                                          stop_speech_token=dims.stop_speech_token)
+    try:
+        for U in utts:
+            embs = [synth.synth_embeds(rpu, 9 + (u % 5), dims.hidden_size, 700 + u) for u in range(U)]
+            a, forced = _run(staged, embs, n)
+            b, _ = _run(as_all, embs, n, forced)
+            c, _ = _run(as_dflt, embs, n, forced)
+            for i in range(n + 1):
+                assert rel_err(b[i], a[i]) < F32_AS_VS_STAGED_TOL, (name, U, i, rel_err(b[i], a[i]))
+                assert rel_err(c[i], a[i]) < F32_AS_VS_STAGED_TOL, (name, U, i, rel_err(c[i], a[i]))
+    finally:
+        for m in (staged, as_all, as_dflt):
+            m.close()
+
+
 def test_activation_stationary_gemm_is_deterministic():
     """The K slices meet in LDS in a fixed order and the K-split slabs are folded in a fixed order: two sessions over
     the same batch give bit-identical logits."""
