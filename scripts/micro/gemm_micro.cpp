@@ -79,7 +79,7 @@ int main(int argc, char** argv) {
                           {"head_store", t3k::EPI_STORE, 8194, d}};
     for (const Case& c : cases) {
         for (int i = 0; i < NCOPY; ++i)
-            CK(t3k::launch_weight_fragments(W + (size_t)i * wmax, Wf + (size_t)i * wmax, c.N, c.K, c.epi, st));
+            CK(t3k::launch_weight_fragments(W + (size_t)i * wmax, Wf + (size_t)i * wmax, c.N, c.K, c.epi, 1, st));
         CK(hipStreamSynchronize(st));
         if (t3k::weight_fragment_elems(c.N, c.K, c.epi) > wmax) { printf("fragment copy too large\n"); return 1; }
         for (int v = 0; v < 2; ++v) {   // v = 0: LDS-staged kernels, v = 1: activation-stationary
