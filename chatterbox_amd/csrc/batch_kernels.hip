@@ -1080,7 +1080,9 @@ __global__ __launch_bounds__(64) void fragment_weights_kernel(const T* __restric
 
 constexpr int kAsRedStride = 20;   // floats per (row) of the reduction buffer: the 4 lane groups of a store hit 4 x 16 distinct banks
 
-template <int EPI, typename T, int NSUB, int KB, int MC>
+// NRM: split RMS norm (GemmArgs): 0 none, 1 consumer (row scales from row_ss), 2 producer (EPI_RESID: next_act / next_ss) -- a
+// template argument, not a run-time test: with the tests in the common kernel every launch measured 2 % slower.
+template <int EPI, typename T, int NSUB, int KB, int MC, int NRM = 0>
 __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte piece: 8 (bf16) or 4 (fp32)
     constexpr int KS = 4 * E;                // k per step (64 B of a row): 32 or 16
@@ -1093,8 +1095,10 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     constexpr int LDA = KB + E;              // LDS row stride in elements (+16 B: 16-row fragment reads fall in distinct banks)
     constexpr int RS = kAsRedStride;
     static_assert(NPH >= 2 && NPH <= 8, "2 to 8 staging phases");
+    constexpr int kLdsMain = (MC * LDA * (int)sizeof(T)) > (8 * MC * RS * 4) ? (MC * LDA * (int)sizeof(T)) : (8 * MC * RS * 4);
     extern __shared__ __attribute__((aligned(16))) unsigned char as_raw[];
     T* lds = reinterpret_cast<T*>(as_raw);   // [MC][LDA], later float red[KW][NSUB][MC][RS]
+    float* rs_s = reinterpret_cast<float*>(as_raw + kLdsMain);   // [MC] row scales of the split norm, behind both
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = lane & 15, g = lane >> 4;
     const int sub = wave % NSUB, kw = wave / NSUB;
@@ -1119,7 +1123,11 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
         }
     }
     // this wave's weight fragments: sub-tile qs, k-steps 8 q + JQ kw + jj of the block's range (1 KB each, contiguous per wave)
-    int qs = blockIdx.x * NSUB + sub;
+    // producer of the split norm: XCD j (blocks with id % 8 == j) owns a run of consecutive feature tiles, so that every 128-byte
+    // line of the rows it writes (fp32 y and the activation-type copy) is written inside one XCD's L2, not in 32-64-byte pieces
+    // from several
+    const int bx = (NRM == 2 && (gridDim.x & 7) == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    int qs = bx * NSUB + sub;
     qs = qs < 2 * tiles32 ? qs : 2 * tiles32 - 1;
     const u32x4* wp = reinterpret_cast<const u32x4*>(a.Wf) + ((size_t)qs * (K / KS) + (size_t)kz * (KB / KS) + kw * JQ) * 64 + lane;
     u32x4 wf[JW];
@@ -1127,6 +1135,16 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     for (int q = 0; q < NPH; ++q)
 #pragma unroll
         for (int jj = 0; jj < JQ; ++jj) wf[q * JQ + jj] = wp[(size_t)(q * 8 + jj) * 64];
+    // split norm, consumer side: thread (row = tid / 16, j = tid % 16) fetches the partial sums of squares of tiles j and j + 16
+    // of its row (requested last, used after the last phase: they are never waited for early)
+    float ssa = 0.f, ssb = 0.f;
+    if (NRM == 1 && (tid >> 4) < MC) {   // wave-uniform
+        int row = m0 + (tid >> 4);
+        row = row < a.M ? row : a.M - 1;
+        const int j = tid & 15;
+        if (j < a.row_ss_tiles) ssa = a.row_ss[(size_t)j * a.M + row];
+        if (j + 16 < a.row_ss_tiles) ssb = a.row_ss[(size_t)(j + 16) * a.M + row];
+    }
     __builtin_amdgcn_sched_barrier(0);   // keep the loads above the stores below (the compiler otherwise sinks the weight loads)
     T* sdst = lds + (tid >> 5) * LDA + (tid & 31) * E;
 #pragma unroll
@@ -1179,6 +1197,12 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     phase(std::integral_constant<int, 6>{});
     phase(std::integral_constant<int, 7>{});
     if (dbg) dbg[2] = wall_clock64();
+    if constexpr (NRM == 1) {   // 16 lanes per row add their partial sums in a fixed butterfly order
+        float sv = ssa + ssb;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sv += __shfl_xor(sv, o, 64);
+        if ((tid & 15) == 0 && (tid >> 4) < MC) rs_s[tid >> 4] = 1.0f / sqrtf(sv / (float)K + a.norm_eps);
+    }
     float* red = reinterpret_cast<float*>(as_raw);   // the buffer becomes the reduction area
     {
         float* rb = red + (size_t)((kw * NSUB + sub) * MC) * RS + nl;
@@ -1203,7 +1227,7 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     for (int i = 0; i < NIT; ++i) {
         const int it = tid + 512 * i;
         const int row = (it >> 4) % MC, p = ((it >> 4) / MC) % (NSUB / 2);
-        const int tile = blockIdx.x * (NSUB / 2) + p;
+        const int tile = bx * (NSUB / 2) + p;
         mi_[i] = m0 + row;
         ok_[i] = it < ITEMS && tile < tiles32 && mi_[i] < a.M;
         tile_[i] = tile < tiles32 ? tile : tiles32 - 1;
@@ -1213,9 +1237,43 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
             s0 += red[(size_t)(((w * NSUB + 2 * p) * MC) + row) * RS + c];
             s1 += red[(size_t)(((w * NSUB + 2 * p + 1) * MC) + row) * RS + c];
         }
+        if constexpr (NRM == 1) {
+            const float rsr = rs_s[row];
+            s0 *= rsr; s1 *= rsr;
+        }
         v0[i] = s0; v1[i] = s1;
         er[i] = rows_pos<EPI>(a, ok_[i] ? mi_[i] : a.M);
         ec[i] = cols_bias<EPI>(a, tile_[i], c);
+    }
+    if constexpr (EPI == EPI_RESID && NRM == 2) {
+        {   // split norm, producer side (unsplit K, N % 32 == 0: every column of a tile is a feature)
+            float rv0[NIT], rv1[NIT], w0[NIT], w1[NIT];
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {   // all loads before the first store (resid may alias y)
+                const size_t o = (size_t)(ok_[i] ? mi_[i] : 0) * a.ldy + 32 * tile_[i] + c;
+                rv0[i] = a.resid[o]; rv1[i] = a.resid[o + 16];
+                w0[i] = a.next_norm_w[32 * tile_[i] + c]; w1[i] = a.next_norm_w[32 * tile_[i] + 16 + c];
+            }
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                float x0 = v0[i], x1 = v1[i];
+                if (a.bias != nullptr) { x0 = __fadd_rn(x0, ec[i].b0); x1 = __fadd_rn(x1, ec[i].b1); }
+                x0 = __fadd_rn(rv0[i], x0); x1 = __fadd_rn(rv1[i], x1);
+                float sq = ok_[i] ? fmaf(x0, x0, x1 * x1) : 0.f;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);   // the 16 columns of (tile, row): lanes c = 0..15
+                if (ok_[i]) {
+                    const size_t o = (size_t)mi_[i] * a.ldy + 32 * tile_[i] + c;
+                    a.y[o] = x0; a.y[o + 16] = x1;
+                    T* na = static_cast<T*>(a.next_act) + (size_t)mi_[i] * a.N + 32 * tile_[i] + c;
+                    Act<T>::store(na, __fmul_rn(w0[i], x0));
+                    Act<T>::store(na + 16, __fmul_rn(w1[i], x1));
+                    if (c == 0) a.next_ss[(size_t)tile_[i] * a.M + mi_[i]] = sq;
+                }
+            }
+            if (dbg) dbg[3] = wall_clock64();
+            return;
+        }
     }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) cs[i] = rope_cs<EPI>(a, tile_[i], c, er[i].pos);
@@ -1334,22 +1392,22 @@ inline int tiles32_of(int N) {
     return (N + 31) / 32;
 }
 
-template <int EPI, typename T, int NSUB, int KB, int MC>
+template <int EPI, typename T, int NSUB, int KB, int MC, int NRM = 0>
 hipError_t launch_gemm_as_v(const GemmArgs& a, int tiles32, int gz, hipStream_t s) {
     constexpr int lds_a = MC * (KB * (int)sizeof(T) + 16), lds_r = 8 * MC * kAsRedStride * 4;
-    constexpr int lds = lds_a > lds_r ? lds_a : lds_r;   // bf16: 66,048 B at KB = 1024, MC = 32
+    constexpr int lds = (lds_a > lds_r ? lds_a : lds_r) + MC * 4;   // + the split norm's row scales; bf16: 66,176 B at KB = 1024, MC = 32
     static bool attr_done[64] = {};   // one flag per instantiation and device
     int dev = 0;
     hipError_t ed = hipGetDevice(&dev);
     if (ed != hipSuccess) return ed;
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_as_kernel<EPI, T, NSUB, KB, MC>),
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_as_kernel<EPI, T, NSUB, KB, MC, NRM>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e0 != hipSuccess) return e0;
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const dim3 grid((2 * tiles32 + NSUB - 1) / NSUB, (a.M + MC - 1) / MC, gz);
-    hipLaunchKernelGGL((gemm_as_kernel<EPI, T, NSUB, KB, MC>), grid, dim3(512), lds, s, a, tiles32);
+    hipLaunchKernelGGL((gemm_as_kernel<EPI, T, NSUB, KB, MC, NRM>), grid, dim3(512), lds, s, a, tiles32);
     return hipGetLastError();
 }
 
@@ -1367,6 +1425,18 @@ inline int as_chunk_rows(int M) { return M <= 32 ? 16 : 32; }
 
 template <int EPI, typename T, int NSUB, int KB>
 hipError_t launch_gemm_as_m(const GemmArgs& a, int tiles32, int gz, hipStream_t s) {
+    if constexpr (EPI == EPI_SWIGLU) {
+        if (a.row_ss != nullptr) {
+            if (as_chunk_rows<T>(a.M) == 16) return launch_gemm_as_v<EPI, T, NSUB, KB, 16, 1>(a, tiles32, gz, s);
+            return launch_gemm_as_v<EPI, T, NSUB, KB, 32, 1>(a, tiles32, gz, s);
+        }
+    }
+    if constexpr (EPI == EPI_RESID) {
+        if (a.next_act != nullptr) {
+            if (as_chunk_rows<T>(a.M) == 16) return launch_gemm_as_v<EPI, T, NSUB, KB, 16, 2>(a, tiles32, gz, s);
+            return launch_gemm_as_v<EPI, T, NSUB, KB, 32, 2>(a, tiles32, gz, s);
+        }
+    }
     if (as_chunk_rows<T>(a.M) == 16) return launch_gemm_as_v<EPI, T, NSUB, KB, 16>(a, tiles32, gz, s);
     return launch_gemm_as_v<EPI, T, NSUB, KB, 32>(a, tiles32, gz, s);
 }
@@ -1390,6 +1460,8 @@ hipError_t launch_gemm_as(const GemmArgs& a, hipStream_t s, bool& handled) {
     if (KB == 0) return hipSuccess;
     const int gz = a.K / KB;
     if (gz > 8 || (gz > 1 && (size_t)gz * a.M * a.N > a.part_floats)) return hipSuccess;
+    if (a.next_act != nullptr && (EPI != EPI_RESID || gz != 1 || (a.N % 32) || !a.next_norm_w || !a.next_ss)) return hipSuccess;
+    if (a.row_ss != nullptr && (EPI != EPI_SWIGLU || a.row_ss_tiles < 1 || a.row_ss_tiles > 32)) return hipSuccess;
     const bool four = (long long)((2 * tiles32 + 3) / 4) * chunks * gz >= kAsMinBlocks;
     handled = true;
     hipError_t e;
@@ -1536,6 +1608,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
         const hipError_t e = wdtype == 1 ? launch_gemm_as_e<uint16_t>(a, epilogue, s, handled) : launch_gemm_as_e<float>(a, epilogue, s, handled);
         if (handled || e != hipSuccess) return e;
     }
+    if (a.next_act != nullptr || a.row_ss != nullptr) return hipErrorInvalidValue;   // only the activation-stationary kernel has the split norm
     constexpr int wide_min = 256;
     if (wdtype == 1 && a.M >= wide_min && a.K % 128 == 0 && (epilogue != EPI_SWIGLU || a.N % 32 == 0) &&
         gemm_wide_pays(a, epilogue)) {
@@ -1569,6 +1642,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
     if (wdtype == 2) return launch_gemm_g<GemmBF16W>(a, epilogue, s);   // bf16 weights, fp32 activation rows
     return wdtype == 1 ? launch_gemm_g<GemmBF16>(a, epilogue, s) : launch_gemm_g<GemmF32>(a, epilogue, s);
 }
+
+bool gemm_as_takes(int M, int K) { return M > 0 && M <= kAsMaxRows && (K == 1024 || K == 512); }
 
 size_t weight_fragment_elems(int N, int K, int epilogue) {
     const int t = epilogue == EPI_ROPE_KV ? (N / kHeadDim) * 2 : (N + 31) / 32;

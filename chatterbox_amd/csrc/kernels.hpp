@@ -79,6 +79,17 @@ struct GemmArgs {
     const void* Wf = nullptr;     // the same matrix fragment-major (launch_weight_fragments with this launch's epilogue and type), or nullptr
     const void* A = nullptr;      // [M, K] activation rows: float (fp32 weights) or bf16 (bf16 weights)
     int M = 0, N = 0, K = 0;
+    // Split RMS norm (activation-stationary kernel only; launch_gemm fails if it would run another kernel).
+    // Producer -- an unsplit EPI_RESID launch: besides y it writes next_act[m][f] = next_norm_w[f] * y[m][f] in the activation
+    // type and next_ss[t][m] = the sum of y[m][f]^2 over the 32 features of tile t (N / 32 tiles).
+    void* next_act = nullptr;
+    const float* next_norm_w = nullptr;
+    float* next_ss = nullptr;
+    // Consumer -- A holds such rows: output row m is scaled by 1 / sqrt(sum_t row_ss[t][m] / K + norm_eps) before the epilogue
+    // (the GEMM is linear in its rows), which completes w * x * rsqrt(mean(x^2) + eps) without a norm launch.
+    const float* row_ss = nullptr;
+    int row_ss_tiles = 0;
+    float norm_eps = 0.f;
     float* y = nullptr;           // EPI_STORE / EPI_RESID output [M, ldy] fp32
     const float* resid = nullptr; // may alias y
     int ldy = 0;
@@ -161,6 +172,9 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t 
 // rows; GemmArgs::Wf): per 16-feature sub-tile (in the partner order of `epilogue`) and 64-byte k-step, the 64 x 16 B of
 // one MFMA operand.  weight_fragment_elems = elements of the copy (N rounded up to whole 32-feature tiles).
 constexpr int kAsMaxRows = 1024;
+// true when a launch with Wf set, M rows and this K runs on the activation-stationary kernel with K unsplit (the shape the split
+// norm needs on both sides)
+bool gemm_as_takes(int M, int K);
 size_t weight_fragment_elems(int N, int K, int epilogue);
 hipError_t launch_weight_fragments(const void* W, void* out, int N, int K, int epilogue, int wdtype, hipStream_t s);
 // row norms of the many-row path; with ks > 0 they first complete x from the K-split partial slabs of the residual

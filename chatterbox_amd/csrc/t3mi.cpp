@@ -114,6 +114,7 @@ struct Session {
     bool gemm_mode = false;     // > 4 activation rows: linears run as MFMA GEMMs (batch_kernels.hip)
     bool kv_bf16 = false;       // KV slabs hold bf16 (many-row regime with bf16 weights), else fp32
     DevBuf gpart;               // GEMM-path K-split partial sums: [<= 8][rows][d] fp32
+    DevBuf rowss;               // split norm: [d / 32][<= kAsMaxRows] partial sums of squares of the residual rows
     int pend_ks = 0;            // the decode step's last down_proj left its fold to the head's norm launch
     const float* pend_bias = nullptr;
     DevBuf xn, attn_out, hact;  // GEMM-path activation rows (float with fp32 weights, bf16 with bf16 weights)
@@ -141,16 +142,17 @@ struct t3mi_model {
     DevBuf wbuf, small, emb, pos_emb, rope_cos, rope_sin;
     DevBuf wfrag;                      // bf16 models: the streamed matrices once more, fragment-major, at wbuf's offsets (build_fragments)
     int as_mask = 15;                  // which GEMMs may take it: 1 qkv, 2 o_proj, 4 gate_up / c_fc, 8 down, 16 head
+    bool norm_split = true;            // T3MI_NORM_SPLIT=0: Llama's post-attention norm stays a launch of its own
     bool as_forced = false;            // T3MI_AS=<mask> set: exactly the named GEMMs take it at every row count the kernel accepts (tests, A/B runs)
     // The fragment-major twin of a matrix in wbuf for a launch of M rows, or nullptr (the LDS-staged kernels then run).
     // Row ranges per GEMM, measured over 400-step sessions (profiles/r02_gemm_as_ab.txt).  bf16: qkv wins up to 1024
     // rows, gate_up up to 512, down up to 384 (at 512 it loses 0.1 ms per step), o_proj from 96 rows (below, its K-split
     // LDS-staged form is 1 % ahead); the head only when T3MI_AS names it (no faster at any size).  fp32 (exact-fp32
     // MFMA, 16x the matrix-core time per product): qkv up to 1024 rows, gate_up up to 96, down up to 128, o_proj never.
-    const void* frag(const void* w, int which, int M) const {
+    const void* frag(const void* w, int which, int M, bool any_rows = false) const {
         if (!wfrag.p || !(as_mask & which)) return nullptr;
         int lo = 1, hi = 0;
-        if (as_forced) which = 0;   // no tuned range: the kernel's own limit
+        if (as_forced || any_rows) which = 0;   // no tuned range: the kernel's own limit
         if (wdtype == T3MI_W_BF16) {
             switch (which) {
                 case 1: hi = 1024; break;
@@ -692,6 +694,7 @@ int build_fragments(t3mi_model* m) {
         m->as_mask = std::atoi(e) & 31;
         m->as_forced = true;
     }
+    if (const char* e = std::getenv("T3MI_NORM_SPLIT")) m->norm_split = e[0] != '0';
     if (m->as_mask == 0) return T3MI_OK;
     const int d = m->d, F = m->F, V = m->V;
     const bool turbo = m->variant == T3MI_VARIANT_TURBO;
@@ -853,6 +856,7 @@ struct GemmCtx {
     const int* rowmap = nullptr;
     float *pm = nullptr, *pl = nullptr, *pacc = nullptr;
     int kps = 64, n_split = 1;
+    float* row_ss = nullptr;   // split norm scratch (Session::rowss), or nullptr: every norm is a launch
     // K-split residual GEMM whose partial slabs are still to be folded into x (by the next norm launch)
     int pend_ks = 0;
     const float* pend_bias = nullptr;
@@ -895,11 +899,24 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
             HIPCHK(t3k::launch_attn_rows(a, st));
         }
         if (tm) tm->mark(K_ATTN);
+        // Llama: the post-attention RMS norm is split over its neighbours when both run on the activation-stationary kernel
+        // with K unsplit -- o_proj's epilogue writes w_ln * x in the activation type and per-tile sums of x^2, gate_up scales
+        // its output rows by 1 / sqrt(mean(x^2) + eps) -- which removes the norm launch (4.7 us per layer in the graph)
+        const void* gu_f = as_ok ? m->frag(lw.wgu, 4, c.M) : nullptr;
+        const void* wo_f = as_ok ? m->frag(lw.wo, 2, c.M) : nullptr;
+        bool split_ln2 = false;
+        // (measured, bf16, ms per step without -> with: 4 utterances 0.929 -> 0.875, 16: 1.056 -> 1.009, 32: 1.303 -> 1.293, 64: 1.804 ->
+        // 1.773, 96: 2.349 -> 2.340, 128: 2.764 -> 2.762, 192: 3.741 -> 3.753: up to 128 rows)
+        if (!turbo && m->norm_split && c.row_ss != nullptr && gu_f != nullptr && d % 32 == 0 && d / 32 <= 32 && c.M <= 128 && t3k::gemm_as_takes(c.M, d)) {
+            const void* any = m->frag(lw.wo, 2, c.M, true);   // o_proj below its tuned row range still pays for itself here
+            if (any != nullptr) { wo_f = any; split_ln2 = true; }
+        }
         {
             t3k::GemmArgs a;
-            a.W = lw.wo; a.Wf = as_ok ? m->frag(lw.wo, 2, c.M) : nullptr; a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
+            a.W = lw.wo; a.Wf = wo_f; a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
             a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_o;
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
+            if (split_ln2) { a.next_act = c.xn; a.next_norm_w = lw.ln2; a.next_ss = c.row_ss; }
             int ks = 1;
             a.ks_out = &ks;
             HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, wdt, st));
@@ -907,13 +924,16 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
             c.pend_bias = lw.b_o;
         }
         if (tm) tm->mark(K_OPROJ);
-        if (turbo) HIPCHK(t3k::launch_layernorm_rows(c.x, lw.ln2, lw.ln2_b, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias));
-        else HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln2, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias));
-        c.pend_ks = 0;
+        if (!split_ln2) {
+            if (turbo) HIPCHK(t3k::launch_layernorm_rows(c.x, lw.ln2, lw.ln2_b, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias));
+            else HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln2, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias));
+            c.pend_ks = 0;
+        }
         {
             t3k::GemmArgs a;
-            a.W = lw.wgu; a.Wf = as_ok ? m->frag(lw.wgu, 4, c.M) : nullptr; a.A = c.xn; a.M = c.M; a.N = turbo ? F : 2 * F; a.K = d; a.yact = c.hact;
+            a.W = lw.wgu; a.Wf = gu_f; a.A = c.xn; a.M = c.M; a.N = turbo ? F : 2 * F; a.K = d; a.yact = c.hact;
             a.bias = lw.b_fc;
+            if (split_ln2) { a.row_ss = c.row_ss; a.row_ss_tiles = d / 32; a.norm_eps = m->eps; }
             HIPCHK(t3k::launch_gemm(a, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, wdt, st));
         }
         if (tm) tm->mark(K_GATEUP);
@@ -946,6 +966,7 @@ GemmCtx decode_ctx(Session* s) {
     c.posmap = s->rowpos.as<int>(); c.rowmap = nullptr;
     c.pm = s->pm.as<float>(); c.pl = s->pl.as<float>(); c.pacc = s->pacc.as<float>();
     c.kps = s->kps; c.n_split = s->n_split;
+    c.row_ss = s->rowss.as<float>();
     return c;
 }
 
@@ -1289,6 +1310,7 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         for (int u = 0; u < n_utt; ++u) items += (size_t)rpu * s0[u];
         const size_t part_rows = std::max<size_t>(s->gemm_mode ? rows : 0, items <= 1024 ? items : 0);
         HIPCHK(s->gpart.alloc(part_rows ? 8 * part_rows * d * 4 : 16));
+        HIPCHK(s->rowss.alloc((size_t)(d / 32 + 1) * t3k::kAsMaxRows * 4));
     }
     HIPCHK(s->logits.alloc(rows * V * 4));
     HIPCHK(s->rowpos.alloc(rows * 4));

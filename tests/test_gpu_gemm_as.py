@@ -120,6 +120,37 @@ def test_fp32_activation_stationary_gemm_equals_staged_gemm(name, turbo, dims, u
             m.close()
 
 
+@pytest.mark.parametrize("dtype,tol", [("bf16", AS_VS_STAGED_TOL), ("f32", F32_AS_VS_STAGED_TOL)])
+def test_split_rms_norm_equals_the_norm_launch(dtype, tol):
+    """Llama's post-attention RMS norm split over o_proj's epilogue (w_ln * x rows + per-tile sums of x^2) and gate_up's row
+    scale, against the same kernels with the norm as a launch of its own (T3MI_NORM_SPLIT=0): full-size model, 6 to 128
+    rows (16- and 32-row chunks, a ragged last chunk).  bf16: the split form rounds w * x where the launch rounds
+    w * x * scale -- the same error class; fp32: sums in another order only."""
+    dims = synth.FULL
+    path = synth.ensure_checkpoint(dims, 1234)
+    old = os.environ.get("T3MI_NORM_SPLIT")
+    os.environ["T3MI_NORM_SPLIT"] = "0"
+    try:
+        plain = cb.load_t3(path, device=0, dtype=dtype)
+    finally:
+        if old is None:
+            del os.environ["T3MI_NORM_SPLIT"]
+        else:
+            os.environ["T3MI_NORM_SPLIT"] = old
+    split = cb.load_t3(path, device=0, dtype=dtype)
+    try:
+        for U in (3, 11, 27, 64):
+            embs = [synth.synth_embeds(2, 9 + (u % 5), dims.hidden_size, 900 + u) for u in range(U)]
+            a, forced = _run(plain, embs, 3)
+            b, _ = _run(split, embs, 3, forced)
+            for i in range(4):
+                assert np.isfinite(b[i]).all()
+                assert rel_err(b[i], a[i]) < tol, (dtype, U, i, rel_err(b[i], a[i]))
+    finally:
+        plain.close()
+        split.close()
+
+
 def test_activation_stationary_gemm_is_deterministic():
     """The K slices meet in LDS in a fixed order and the K-split slabs are folded in a fixed order: two sessions over
     the same batch give bit-identical logits."""
