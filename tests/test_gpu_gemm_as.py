@@ -7,8 +7,8 @@ The two bf16 kernels multiply the same bf16 operands and accumulate in fp32; the
 sums (K slices per wave, reduced in LDS).  A sum that differs in its last fp32 bit can flip the bf16 rounding of an
 activation (1 part in 256), and 30 layers carry such flips forward, so the two bf16 paths agree to AS_VS_STAGED_TOL of
 max |logit| (half the bf16 bar; measured up to 0.7 %), and each stays inside the bf16 bar against the fp32 path, the
-new kernel no further from it than the old one (within 1.5x).  Every shape class of the launch heuristic is covered: 16-, 32- and 64-row chunks, one chunk and two, the
-K-split residual GEMM with 1024-k and 512-k slabs (d_ff 4096 at full size, K = 1024 unsplit at tiny size), the
+new kernel no further from it than the old one (within 1.5x).  Every shape class of the launch heuristic is covered:
+16- and 32-row chunks, 1 to 32 chunks, a ragged last chunk, the K-split residual GEMM with 1024-k and 512-k slabs (d_ff 4096 at full size, K = 1024 unsplit at tiny size), the
 4- and 2-sub-tile blocks, a head whose vocabulary is not a multiple of 32 (mask 16: last tile partly empty), and
 Turbo's bias / GELU / no-RoPE epilogues."""
 import os
