@@ -2,8 +2,14 @@
 (SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES).
 
 usage: python scripts/pmc_mfma.py <counter_collection.csv>
-MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs)   (the gfx94x derived-counter formula the
-guide says gfx950 falls back to, MI355X_MICROARCH.md 'rocprofv3 PMC slots')."""
+
+Units, calibrated on a kernel whose MFMA count is known (round 2: the prefill gate_up GEMM of 512 prompts, 65536 rows x
+8192 x 1024 = 67.1 M v_mfma_f32_16x16x32_bf16): SQ_VALU_MFMA_BUSY_CYCLES reads 536.9 M = 8 per MFMA, while one such
+MFMA occupies a SIMD's matrix core for 16 clocks at the 2.5 PFLOP/s dense rating (8192 MACs / 509 MACs per clock and
+SIMD) -- the counter ticks every second clock; GRBM_GUI_ACTIVE is the SUM over the 8 XCDs (15-25 "GHz" against the
+kernel's wall time).  So
+    MfmaUtil = 2 * SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8) * 256 CUs * 4 SIMDs),
+16 x the gfx94x derived-counter formula (BUSY / (GUI * CUs * 4)) that round 1 printed as "raw".  Both are reported."""
 import csv
 import json
 import sys
@@ -14,7 +20,11 @@ acc = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(set)
 for r in rows:
     n = r["Kernel_Name"]
-    if "gemm_rows_kernel<" in n:
+    if "gemm_as_kernel<" in n:
+        k = "gemm_as<" + n.split("gemm_as_kernel<")[1].split(">")[0] + ">"
+    elif "gemm_wide_kernel<" in n:
+        k = "gemm_wide<" + n.split("gemm_wide_kernel<")[1].split(">")[0] + ">"
+    elif "gemm_rows_kernel<" in n:
         k = "gemm_rows<" + n.split("gemm_rows_kernel<")[1].split(">")[0] + ">"
     elif "attn_rows_kernel" in n:
         k = "attn_rows"
@@ -33,5 +43,6 @@ for k, c in acc.items():
     out[k] = {"dispatches": len(calls[k]), "GRBM_GUI_ACTIVE": int(gui), "SQ_VALU_MFMA_BUSY_CYCLES": int(busy),
               "SQ_INSTS_VALU_MFMA_MOPS_BF16": int(c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)),
               "SQ_BUSY_CU_CYCLES": int(c.get("SQ_BUSY_CU_CYCLES", 0.0)),
-              "MfmaUtil_percent": round(100.0 * busy / (gui * 256 * 4), 3) if gui else None}
+              "MfmaUtil_raw_gfx94x_formula_percent": round(100.0 * busy / (gui * 256 * 4), 3) if gui else None,
+              "MfmaUtil_percent": round(100.0 * 2 * busy / (gui / 8 * 256 * 4), 2) if gui else None}
 print(json.dumps(out, indent=1))
