@@ -3,13 +3,14 @@
 
 usage: python scripts/pmc_mfma.py <counter_collection.csv>
 
-Units, calibrated on a kernel whose MFMA count is known (round 2: the prefill gate_up GEMM of 512 prompts, 65536 rows x
-8192 x 1024 = 67.1 M v_mfma_f32_16x16x32_bf16): SQ_VALU_MFMA_BUSY_CYCLES reads 536.9 M = 8 per MFMA, while one such
-MFMA occupies a SIMD's matrix core for 16 clocks at the 2.5 PFLOP/s dense rating (8192 MACs / 509 MACs per clock and
-SIMD) -- the counter ticks every second clock; GRBM_GUI_ACTIVE is the SUM over the 8 XCDs (15-25 "GHz" against the
-kernel's wall time).  So
-    MfmaUtil = 2 * SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8) * 256 CUs * 4 SIMDs),
-16 x the gfx94x derived-counter formula (BUSY / (GUI * CUs * 4)) that round 1 printed as "raw".  Both are reported."""
+Units, calibrated on a kernel whose MFMA count is known (round 2: one prefill group's gate_up GEMM, 32768 rows x 8192 x
+1024 = 33.55 M v_mfma_f32_16x16x32_bf16): SQ_VALU_MFMA_BUSY_CYCLES reads 536.9 M = 16 per MFMA, the clocks one such
+MFMA occupies a SIMD's matrix core at the 2.5 PFLOP/s dense rating (8192 MACs / 509 MACs per clock and SIMD);
+GRBM_GUI_ACTIVE is the SUM over the 8 XCDs (15-25 "GHz" against the kernel's wall time).  So
+    MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8) * 256 CUs * 4 SIMDs),
+8 x the gfx94x derived-counter formula (BUSY / (GUI * CUs * 4)) that round 1 printed.  Both are reported.  Cross-check on
+the same kernel: 5.5e14 FLOP in 871 us (profiled) = 0.63 PFLOP/s; GUI / 8 = 1.67 M cycles = 1.92 GHz, at which the
+matrix cores peak at 2.0 PFLOP/s: 31 %, the figure the formula gives."""
 import csv
 import json
 import sys
@@ -44,5 +45,5 @@ for k, c in acc.items():
               "SQ_INSTS_VALU_MFMA_MOPS_BF16": int(c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)),
               "SQ_BUSY_CU_CYCLES": int(c.get("SQ_BUSY_CU_CYCLES", 0.0)),
               "MfmaUtil_raw_gfx94x_formula_percent": round(100.0 * busy / (gui * 256 * 4), 3) if gui else None,
-              "MfmaUtil_percent": round(100.0 * 2 * busy / (gui / 8 * 256 * 4), 2) if gui else None}
+              "MfmaUtil_percent": round(100.0 * busy / (gui / 8 * 256 * 4), 2) if gui else None}
 print(json.dumps(out, indent=1))
