@@ -38,9 +38,11 @@ __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint
 template <typename AT> struct Act;
 template <> struct Act<float> {
     __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ float round(float v) { return v; }   // the value store() leaves, as a float
 };
 template <> struct Act<uint16_t> {
     __device__ static __forceinline__ void store(uint16_t* p, float v) { *p = f2bf(v); }
+    __device__ static __forceinline__ float round(float v) { return __uint_as_float((uint32_t)f2bf(v) << 16); }
 };
 
 // fragment loaders / MFMA steps per weight type: one "k-block" = 64 bytes of a row
@@ -312,7 +314,7 @@ template <typename AT>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ b, float eps, AT* __restrict__ out, int d,
                                                              const float* __restrict__ part, int ks, const float* __restrict__ pbias,
-                                                             int M) {
+                                                             int M, float* __restrict__ row_mean) {
     // same 16-byte access shape as rmsnorm_rows_kernel: thread t owns elements 4t..4t+3 of each 1024-element slice
     constexpr int kV = kNormMaxPer / 4;
     __shared__ float sred[8];
@@ -353,6 +355,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(float* __restrict__
     if ((tid & 63) == 0) sred[tid >> 6] = sm;
     __syncthreads();
     const float mean = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / (float)d;
+    if (row_mean != nullptr && tid == 0) row_mean[m] = mean;   // for the LayerNorm split of the next residual GEMM (GemmArgs::resid_mean)
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < kV; ++j) {
@@ -450,6 +453,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_k
     OT* orow = static_cast<OT*>(a.out) + (size_t)qi * d + h * kHeadDim;
     if (pos < 0) {   // inactive item: defined (zero) activation row, as the merge kernel wrote
         if (tid < kHeadDim) Act<OT>::store(orow + tid, 0.f);
+        if (a.dot_out != nullptr && tid == 0) a.dot_out[(size_t)qi * a.n_heads + h] = 0.f;
         return;
     }
     const int L = pos + 1;
@@ -464,6 +468,8 @@ __global__ __launch_bounds__(64 * NW, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_k
         // scores are q.k / sqrt(64): the scale is applied to the dot product (R/llama.R:259)
         qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
     }
+    // (requested here, used after the merge: at the end it would be one more memory latency in every block's tail)
+    const float dv = a.dot_vec != nullptr ? a.dot_vec[h * kHeadDim + lane] : 0.f;
     float m_run = -INFINITY, l_run = 0.f, acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -566,7 +572,14 @@ __global__ __launch_bounds__(64 * NW, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_k
             den = fmaf(ws, sm_l[s2], den);
             o = fmaf(ws, sm_acc[s2][tid], o);
         }
-        Act<OT>::store(orow + tid, o / den);
+        const float ov = o / den;
+        Act<OT>::store(orow + tid, ov);
+        if (a.dot_out != nullptr) {   // (block-uniform) the stored values of this head . dot_vec, for the LayerNorm split of o_proj
+            float pv = Act<OT>::round(ov) * dv;
+#pragma unroll
+            for (int s2 = 32; s2 > 0; s2 >>= 1) pv += __shfl_xor(pv, s2, 64);
+            if (tid == 0) a.dot_out[(size_t)qi * a.n_heads + h] = pv;
+        }
     }
 }
 
@@ -1080,8 +1093,11 @@ __global__ __launch_bounds__(64) void fragment_weights_kernel(const T* __restric
 
 constexpr int kAsRedStride = 20;   // floats per (row) of the reduction buffer: the 4 lane groups of a store hit 4 x 16 distinct banks
 
-// NRM: split RMS norm (GemmArgs): 0 none, 1 consumer (row scales from row_ss), 2 producer (EPI_RESID: next_act / next_ss) -- a
-// template argument, not a run-time test: with the tests in the common kernel every launch measured 2 % slower.
+// NRM: split norm (GemmArgs): 0 none, 1 consumer (row scales from row_ss), 2 producer (EPI_RESID: next_act / next_ss), 3 producer
+// of the LayerNorm form (row means from resid_mean / row_dot / mean_shift) -- a template argument, not a run-time test: with the
+// tests in the common kernel every launch measured 2 % slower.  (A first LayerNorm form computed the products activation row x
+// column means inside this kernel, from the staging registers: 8 more 16-byte loads per thread, o_proj 6.1 us at 8 rows against
+// 4.3 for the K-split LDS-staged kernel; the attention launch has each head's 64 values in registers anyway.)
 template <int EPI, typename T, int NSUB, int KB, int MC, int NRM = 0>
 __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte piece: 8 (bf16) or 4 (fp32)
@@ -1126,7 +1142,7 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     // producer of the split norm: XCD j (blocks with id % 8 == j) owns a run of consecutive feature tiles, so that every 128-byte
     // line of the rows it writes (fp32 y and the activation-type copy) is written inside one XCD's L2, not in 32-64-byte pieces
     // from several
-    const int bx = (NRM == 2 && (gridDim.x & 7) == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    const int bx = (NRM >= 2 && (gridDim.x & 7) == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
     int qs = bx * NSUB + sub;
     qs = qs < 2 * tiles32 ? qs : 2 * tiles32 - 1;
     const u32x4* wp = reinterpret_cast<const u32x4*>(a.Wf) + ((size_t)qs * (K / KS) + (size_t)kz * (KB / KS) + kw * JQ) * 64 + lane;
@@ -1144,6 +1160,17 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
         const int j = tid & 15;
         if (j < a.row_ss_tiles) ssa = a.row_ss[(size_t)j * a.M + row];
         if (j + 16 < a.row_ss_tiles) ssb = a.row_ss[(size_t)(j + 16) * a.M + row];
+    }
+    // LayerNorm producer: thread (row = tid / 16, j = tid % 16) fetches the attention launch's products (attention row of head j
+    // and j + 16) . mean_vec of its row, and the old row mean (requested last as well)
+    float rda = 0.f, rdb = 0.f, mu_old = 0.f;
+    if (NRM == 3 && (tid >> 4) < MC) {   // wave-uniform
+        int row = m0 + (tid >> 4);
+        row = row < a.M ? row : a.M - 1;
+        const int j = tid & 15;
+        if (j < a.row_dot_n) rda = a.row_dot[(size_t)row * a.row_dot_n + j];
+        if (j + 16 < a.row_dot_n) rdb = a.row_dot[(size_t)row * a.row_dot_n + j + 16];
+        mu_old = a.resid_mean[row];
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the loads above the stores below (the compiler otherwise sinks the weight loads)
     T* sdst = lds + (tid >> 5) * LDA + (tid & 31) * E;
@@ -1203,6 +1230,12 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
         for (int o = 1; o < 16; o <<= 1) sv += __shfl_xor(sv, o, 64);
         if ((tid & 15) == 0 && (tid >> 4) < MC) rs_s[tid >> 4] = 1.0f / sqrtf(sv / (float)K + a.norm_eps);
     }
+    if constexpr (NRM == 3) {   // rs_s[row] = the new row mean; 16 lanes per row add the heads' products in a fixed butterfly order
+        float sv = rda + rdb;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sv += __shfl_xor(sv, o, 64);
+        if ((tid & 15) == 0 && (tid >> 4) < MC) rs_s[tid >> 4] = mu_old + (sv + a.mean_shift);
+    }
     float* red = reinterpret_cast<float*>(as_raw);   // the buffer becomes the reduction area
     {
         float* rb = red + (size_t)((kw * NSUB + sub) * MC) * RS + nl;
@@ -1245,7 +1278,7 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
         er[i] = rows_pos<EPI>(a, ok_[i] ? mi_[i] : a.M);
         ec[i] = cols_bias<EPI>(a, tile_[i], c);
     }
-    if constexpr (EPI == EPI_RESID && NRM == 2) {
+    if constexpr (EPI == EPI_RESID && NRM >= 2) {
         {   // split norm, producer side (unsplit K, N % 32 == 0: every column of a tile is a feature)
             float rv0[NIT], rv1[NIT], w0[NIT], w1[NIT];
 #pragma unroll
@@ -1259,15 +1292,20 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
                 float x0 = v0[i], x1 = v1[i];
                 if (a.bias != nullptr) { x0 = __fadd_rn(x0, ec[i].b0); x1 = __fadd_rn(x1, ec[i].b1); }
                 x0 = __fadd_rn(rv0[i], x0); x1 = __fadd_rn(rv1[i], x1);
-                float sq = ok_[i] ? fmaf(x0, x0, x1 * x1) : 0.f;
+                float z0 = x0, z1 = x1;   // LayerNorm form: centred on the row mean
+                if constexpr (NRM == 3) {
+                    const float mu = rs_s[((tid + 512 * i) >> 4) % MC];
+                    z0 = x0 - mu; z1 = x1 - mu;
+                }
+                float sq = ok_[i] ? fmaf(z0, z0, z1 * z1) : 0.f;
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);   // the 16 columns of (tile, row): lanes c = 0..15
                 if (ok_[i]) {
                     const size_t o = (size_t)mi_[i] * a.ldy + 32 * tile_[i] + c;
                     a.y[o] = x0; a.y[o + 16] = x1;
                     T* na = static_cast<T*>(a.next_act) + (size_t)mi_[i] * a.N + 32 * tile_[i] + c;
-                    Act<T>::store(na, __fmul_rn(w0[i], x0));
-                    Act<T>::store(na + 16, __fmul_rn(w1[i], x1));
+                    Act<T>::store(na, __fmul_rn(w0[i], z0));
+                    Act<T>::store(na + 16, __fmul_rn(w1[i], z1));
                     if (c == 0) a.next_ss[(size_t)tile_[i] * a.M + mi_[i]] = sq;
                 }
             }
@@ -1425,13 +1463,17 @@ inline int as_chunk_rows(int M) { return M <= 32 ? 16 : 32; }
 
 template <int EPI, typename T, int NSUB, int KB>
 hipError_t launch_gemm_as_m(const GemmArgs& a, int tiles32, int gz, hipStream_t s) {
-    if constexpr (EPI == EPI_SWIGLU) {
+    if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GELU) {
         if (a.row_ss != nullptr) {
             if (as_chunk_rows<T>(a.M) == 16) return launch_gemm_as_v<EPI, T, NSUB, KB, 16, 1>(a, tiles32, gz, s);
             return launch_gemm_as_v<EPI, T, NSUB, KB, 32, 1>(a, tiles32, gz, s);
         }
     }
     if constexpr (EPI == EPI_RESID) {
+        if (a.next_act != nullptr && a.row_dot != nullptr) {
+            if (as_chunk_rows<T>(a.M) == 16) return launch_gemm_as_v<EPI, T, NSUB, KB, 16, 3>(a, tiles32, gz, s);
+            return launch_gemm_as_v<EPI, T, NSUB, KB, 32, 3>(a, tiles32, gz, s);
+        }
         if (a.next_act != nullptr) {
             if (as_chunk_rows<T>(a.M) == 16) return launch_gemm_as_v<EPI, T, NSUB, KB, 16, 2>(a, tiles32, gz, s);
             return launch_gemm_as_v<EPI, T, NSUB, KB, 32, 2>(a, tiles32, gz, s);
@@ -1461,7 +1503,9 @@ hipError_t launch_gemm_as(const GemmArgs& a, hipStream_t s, bool& handled) {
     const int gz = a.K / KB;
     if (gz > 8 || (gz > 1 && (size_t)gz * a.M * a.N > a.part_floats)) return hipSuccess;
     if (a.next_act != nullptr && (EPI != EPI_RESID || gz != 1 || (a.N % 32) || !a.next_norm_w || !a.next_ss)) return hipSuccess;
-    if (a.row_ss != nullptr && (EPI != EPI_SWIGLU || a.row_ss_tiles < 1 || a.row_ss_tiles > 32)) return hipSuccess;
+    if ((a.row_dot != nullptr) != (a.resid_mean != nullptr) || (a.row_dot != nullptr && (a.next_act == nullptr || a.row_dot_n < 1 || a.row_dot_n > 32)))
+        return hipSuccess;
+    if (a.row_ss != nullptr && ((EPI != EPI_SWIGLU && EPI != EPI_GELU) || a.row_ss_tiles < 1 || a.row_ss_tiles > 32)) return hipSuccess;
     const bool four = (long long)((2 * tiles32 + 3) / 4) * chunks * gz >= kAsMinBlocks;
     handled = true;
     hipError_t e;
@@ -1687,14 +1731,14 @@ hipError_t launch_rmsnorm_rows(float* x, const float* w, float eps, void* out, i
 }
 
 hipError_t launch_layernorm_rows(float* x, const float* w, const float* b, float eps, void* out, int M, int d, int act_bf16,
-                                 hipStream_t s, const float* part, int ks, const float* pbias) {
+                                 hipStream_t s, const float* part, int ks, const float* pbias, float* row_mean) {
     if (!x || !w || !b || !out || M <= 0 || d <= 0 || d > 256 * kNormMaxPer || (d & 3) || (ks > 0 && !part)) return hipErrorInvalidValue;
     if (act_bf16)
         hipLaunchKernelGGL(layernorm_rows_kernel<uint16_t>, dim3(M), dim3(256), 0, s, x, w, b, eps, static_cast<uint16_t*>(out), d,
-                           part, ks, pbias, M);
+                           part, ks, pbias, M, row_mean);
     else
         hipLaunchKernelGGL(layernorm_rows_kernel<float>, dim3(M), dim3(256), 0, s, x, w, b, eps, static_cast<float*>(out), d, part,
-                           ks, pbias, M);
+                           ks, pbias, M, row_mean);
     return hipGetLastError();
 }
 
@@ -1707,7 +1751,7 @@ hipError_t launch_fold_partials(float* x, const float* part, int ks, const float
 hipError_t launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
     if (!a.q || !a.kcache || !a.vcache || !a.posmap || !a.out || a.M <= 0 || a.n_heads <= 0 || a.max_len <= 0)
         return hipErrorInvalidValue;
-    if ((long long)a.M * a.n_heads > 0x7FFFFFFFLL) return hipErrorInvalidValue;
+    if ((long long)a.M * a.n_heads > 0x7FFFFFFFLL || (a.dot_vec != nullptr) != (a.dot_out != nullptr)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)a.M * (unsigned)a.n_heads);
     // Waves per (item, head) block by the number of such blocks: 1 from 512 blocks, 2 from 256, else 4.  With one wave per
     // block all 2048 blocks of a 128-row step are resident at once (8 per CU) and start and end at different times; with

@@ -85,6 +85,15 @@ struct GemmArgs {
     void* next_act = nullptr;
     const float* next_norm_w = nullptr;
     float* next_ss = nullptr;
+    // LayerNorm form of the producer (Turbo; resid_mean and row_dot both set, or neither): the row mean is known before the product
+    // is -- mean(y[m]) = resid_mean[m] + A[m] . colmean(W) + mean(bias) -- and the attention launch before o_proj has every head's 64
+    // values of A[m] in registers: it leaves row_dot[m][h] = A[m][64 h .. 64 h + 63] . colmean (AttnRowsArgs::dot_vec / dot_out).
+    // next_act = next_norm_w * (y - mean), next_ss sums (y - mean)^2.  The consumer is the same (its bias must carry W . b_ln, the
+    // LayerNorm bias folded in).
+    const float* resid_mean = nullptr;   // [M] mean of resid[m] (launch_layernorm_rows' row_mean)
+    const float* row_dot = nullptr;      // [M][row_dot_n]
+    int row_dot_n = 0;                   // <= 32
+    float mean_shift = 0.f;              // mean(bias)
     // Consumer -- A holds such rows: output row m is scaled by 1 / sqrt(sum_t row_ss[t][m] / K + norm_eps) before the epilogue
     // (the GEMM is linear in its rows), which completes w * x * rsqrt(mean(x^2) + eps) without a norm launch.
     const float* row_ss = nullptr;
@@ -179,8 +188,10 @@ size_t weight_fragment_elems(int N, int K, int epilogue);
 hipError_t launch_weight_fragments(const void* W, void* out, int N, int K, int epilogue, int wdtype, hipStream_t s);
 // row norms of the many-row path; with ks > 0 they first complete x from the K-split partial slabs of the residual
 // GEMM before them: x[m] += pbias + sum_s part[s][m] (written back)
+// (row_mean: [M] receives the mean of every completed row, or nullptr)
 hipError_t launch_layernorm_rows(float* x, const float* w, const float* b, float eps, void* out, int M, int d, int act_bf16,
-                                 hipStream_t s, const float* part = nullptr, int ks = 0, const float* pbias = nullptr);
+                                 hipStream_t s, const float* part = nullptr, int ks = 0, const float* pbias = nullptr,
+                                 float* row_mean = nullptr);
 hipError_t launch_rmsnorm_rows(float* x, const float* w, float eps, void* out, int M, int d, int act_bf16, hipStream_t s,
                                const float* part = nullptr, int ks = 0, const float* pbias = nullptr);
 hipError_t launch_fold_partials(float* x, const float* part, int ks, const float* pbias, int M, int d, hipStream_t s);
@@ -194,6 +205,8 @@ struct AttnRowsArgs {
     const int* rowmap = nullptr;    // [M] cache row of item m (nullptr = identity)
     void* out = nullptr;            // [M, H*64]
     int M = 0, n_heads = 0, max_len = 0, kv_bf16 = 0, out_bf16 = 0;
+    const float* dot_vec = nullptr; // [H*64] and dot_out [M][H], both or neither: dot_out[m][h] = the stored values of head h . dot_vec's
+    float* dot_out = nullptr;       // slice of head h (GemmArgs::row_dot of the o_proj launch that follows)
 };
 hipError_t launch_attn_rows(const AttnRowsArgs& a, hipStream_t s);
 hipError_t launch_gather_rows(const float* const* src_rows, float* x, int M, int d, hipStream_t s);

@@ -104,6 +104,8 @@ struct LayerW {
     const float* b_fc = nullptr;
     const float* b_qkv_f = nullptr; // bias + W . b_ln  (decode GEMV path: the LayerNorm bias folded in)
     const float* b_fc_f = nullptr;
+    const float* o_colmean = nullptr;   // Turbo: [d] column means of attn.c_proj's weight (AttnRowsArgs::dot_vec)
+    float o_bias_mean = 0.f;            // and the mean of its bias (GemmArgs::mean_shift)
     const float* b_o = nullptr;
     const float* b_down = nullptr;
 };
@@ -114,7 +116,8 @@ struct Session {
     bool gemm_mode = false;     // > 4 activation rows: linears run as MFMA GEMMs (batch_kernels.hip)
     bool kv_bf16 = false;       // KV slabs hold bf16 (many-row regime with bf16 weights), else fp32
     DevBuf gpart;               // GEMM-path K-split partial sums: [<= 8][rows][d] fp32
-    DevBuf rowss;               // split norm: [d / 32][<= kAsMaxRows] partial sums of squares of the residual rows
+    DevBuf rowss;               // split norm: [d / 32][<= kAsMaxRows] partial sums of squares of the residual rows, a spare slab, then
+    float* rowmu = nullptr;     // (inside rowss; Turbo's LayerNorm form) [kAsMaxRows] row means, [<= kAsMaxRows][H <= 32] head products
     int pend_ks = 0;            // the decode step's last down_proj left its fold to the head's norm launch
     const float* pend_bias = nullptr;
     DevBuf xn, attn_out, hact;  // GEMM-path activation rows (float with fp32 weights, bf16 with bf16 weights)
@@ -458,6 +461,35 @@ struct Uploader {
         HIPCHK(hipMemcpy(dst_fold, fold.data(), (size_t)N * 4, hipMemcpyHostToDevice));
         return T3MI_OK;
     }
+    // For the LayerNorm split of a residual GEMM y = resid + W a + b: dst[k] = sum_n W[n][k] / N (W as stored: bf16-rounded for a
+    // bf16 model), bias_mean = mean(b) -- the mean of an output row is then resid's mean + a . dst + bias_mean
+    int put_colmean(const std::string& wname, const std::string& bname, int64_t N, int64_t K, float* dst, float& bias_mean) {
+        std::vector<float> W, b;
+        int rc;
+        if ((rc = fetch(wname, N, K, W))) return rc;
+        if ((rc = fetch(bname, N, -1, b))) return rc;
+        std::vector<double> acc((size_t)K + 1, 0.0);
+        const bool bf = m->wdtype == T3MI_W_BF16;
+        for (int64_t n = 0; n < N; ++n) {
+            const float* wr = W.data() + (size_t)n * K;
+            for (int64_t k = 0; k < K; ++k) {
+                float w = wr[k];
+                if (bf) {
+                    uint32_t u;
+                    std::memcpy(&u, &w, 4);
+                    if ((u & 0x7FFFFFFFu) <= 0x7F800000u) u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+                    std::memcpy(&w, &u, 4);
+                }
+                acc[(size_t)k] += (double)w;
+            }
+            acc[(size_t)K] += (double)b[(size_t)n];
+        }
+        std::vector<float> out((size_t)K);
+        for (int64_t k = 0; k < K; ++k) out[(size_t)k] = (float)(acc[(size_t)k] / (double)N);
+        bias_mean = (float)(acc[(size_t)K] / (double)N);
+        HIPCHK(hipMemcpy(dst, out.data(), (size_t)K * 4, hipMemcpyHostToDevice));
+        return T3MI_OK;
+    }
     // streamed matrix in the model's weight dtype; dst points into wbuf
     int put_w(const std::string& name, int64_t d0, int64_t d1, void* dst) {
         if (skip_w) return T3MI_OK;
@@ -609,8 +641,9 @@ int load_turbo(t3mi_model* m, const t3mi::SafeTensorsFile& st, const char* cache
     const size_t es = m->wdtype == T3MI_W_BF16 ? 2 : 4;
     const size_t per_layer = (3 * d * d + d * d + F * d + d * F) * es;
     const size_t total = per_layer * L + V * d * es;
-    // small: per layer ln1 w,b | ln2 w,b | b_qkv raw,fold | b_o | b_fc raw,fold | b_down ; ln_f w,b ; head bias raw,fold
-    const size_t small_layer = 4 * d + 2 * 3 * d + d + 2 * F + d;
+    // small: per layer ln1 w,b | ln2 w,b | b_qkv raw,fold | b_o | c_proj column means | b_fc raw,fold | b_down ;
+    // ln_f w,b ; head bias raw,fold
+    const size_t small_layer = 4 * d + 2 * 3 * d + d + d + 2 * F + d;
     const size_t small_total = small_layer * L + 2 * d + 2 * V;
     HIPCHK(m->wbuf.alloc(total));
     HIPCHK(m->small.alloc(small_total * 4));
@@ -652,6 +685,9 @@ int load_turbo(t3mi_model* m, const t3mi::SafeTensorsFile& st, const char* cache
         w += d * d * es;
         lw.b_o = sm;
         if ((rc = up.put_f32(p + "attn.c_proj.bias", d, -1, sm))) return rc;
+        sm += d;
+        lw.o_colmean = sm;
+        if ((rc = up.put_colmean(p + "attn.c_proj.weight", p + "attn.c_proj.bias", d, d, sm, lw.o_bias_mean))) return rc;
         sm += d;
         lw.wgu = w;
         if ((rc = up.put_w(p + "mlp.c_fc.weight", F, d, w))) return rc;
@@ -857,6 +893,7 @@ struct GemmCtx {
     float *pm = nullptr, *pl = nullptr, *pacc = nullptr;
     int kps = 64, n_split = 1;
     float* row_ss = nullptr;   // split norm scratch (Session::rowss), or nullptr: every norm is a launch
+    float* row_mu = nullptr;   // [M] row means of x as ln_1 saw it (Turbo's LayerNorm form of the split)
     // K-split residual GEMM whose partial slabs are still to be folded into x (by the next norm launch)
     int pend_ks = 0;
     const float* pend_bias = nullptr;
@@ -878,7 +915,27 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
         char* kc = s->kc.as<char>() + layer_kv * l;
         char* vc = s->vc.as<char>() + layer_kv * l;
         const float* gp = s->gpart.as<float>();
-        if (turbo) HIPCHK(t3k::launch_layernorm_rows(c.x, lw.ln1, lw.ln1_b, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias));
+        // The post-attention norm is split over its neighbours when both run on the activation-stationary kernel with K unsplit:
+        // o_proj's epilogue writes w_ln * x (Turbo: w_ln * (x - mean)) in the activation type and per-tile sums of squares, gate_up /
+        // c_fc scales its output rows by 1 / sqrt(mean + eps) -- which removes the norm launch (4-5 us per layer in the graph).
+        // Turbo's LayerNorm needs the row mean before the product exists: mean(x + W a + b) = mean(x) + a . colmean(W) + mean(b),
+        // with mean(x) from ln_1's launch and the dot product from the attention launch (per head, from the values it stores); its
+        // bias b_ln rides in c_fc's bias (b_fc_f, the copy the <= 4-row path uses).
+        const void* gu_f = as_ok ? m->frag(lw.wgu, 4, c.M) : nullptr;
+        const void* wo_f = as_ok ? m->frag(lw.wo, 2, c.M) : nullptr;
+        bool split_ln2 = false;
+        // (measured, Llama bf16, ms per step without -> with: 4 utterances 0.929 -> 0.875, 16: 1.056 -> 1.009, 32: 1.303 -> 1.293, 64: 1.804 ->
+        // 1.773, 96: 2.349 -> 2.340, 128: 2.764 -> 2.762, 192: 3.741 -> 3.753: up to 128 rows)
+        if (m->norm_split && c.row_ss != nullptr && gu_f != nullptr && d % 32 == 0 && d / 32 <= 32 && c.M <= 128 && t3k::gemm_as_takes(c.M, d) &&
+            (!turbo || (c.row_mu != nullptr && lw.o_colmean != nullptr && H <= 32 && (abf || c.M <= 32)))) {
+            // (Turbo, S0 407, ms per step without -> with; bf16: 8 sentences 0.826 -> 0.787, 16: 0.870 -> 0.830, 32: 0.995 -> 0.953, 64: 1.321 ->
+            // 1.300, 128: 1.991 -> 1.957; fp32: 8: 1.216 -> 1.216, 16: 1.272 -> 1.254, 32: 1.573 -> 1.557, 64: 2.345 -> 2.414: fp32 up to 32 rows)
+            const void* any = m->frag(lw.wo, 2, c.M, true);   // o_proj below its tuned row range still pays for itself here
+            if (any != nullptr) { wo_f = any; split_ln2 = true; }
+        }
+        if (turbo)
+            HIPCHK(t3k::launch_layernorm_rows(c.x, lw.ln1, lw.ln1_b, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias,
+                                              split_ln2 ? c.row_mu : nullptr));
         else HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln1, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias));
         c.pend_ks = 0;
         {
@@ -896,27 +953,17 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
             a.q = c.q; a.kcache = kc; a.vcache = vc; a.posmap = c.posmap; a.rowmap = c.rowmap;
             a.out = c.attn_out; a.M = c.M; a.n_heads = H; a.max_len = s->max_len;
             a.kv_bf16 = s->kv_bf16 ? 1 : 0; a.out_bf16 = abf;
+            if (split_ln2 && turbo) { a.dot_vec = lw.o_colmean; a.dot_out = c.row_mu + t3k::kAsMaxRows; }
             HIPCHK(t3k::launch_attn_rows(a, st));
         }
         if (tm) tm->mark(K_ATTN);
-        // Llama: the post-attention RMS norm is split over its neighbours when both run on the activation-stationary kernel
-        // with K unsplit -- o_proj's epilogue writes w_ln * x in the activation type and per-tile sums of x^2, gate_up scales
-        // its output rows by 1 / sqrt(mean(x^2) + eps) -- which removes the norm launch (4.7 us per layer in the graph)
-        const void* gu_f = as_ok ? m->frag(lw.wgu, 4, c.M) : nullptr;
-        const void* wo_f = as_ok ? m->frag(lw.wo, 2, c.M) : nullptr;
-        bool split_ln2 = false;
-        // (measured, bf16, ms per step without -> with: 4 utterances 0.929 -> 0.875, 16: 1.056 -> 1.009, 32: 1.303 -> 1.293, 64: 1.804 ->
-        // 1.773, 96: 2.349 -> 2.340, 128: 2.764 -> 2.762, 192: 3.741 -> 3.753: up to 128 rows)
-        if (!turbo && m->norm_split && c.row_ss != nullptr && gu_f != nullptr && d % 32 == 0 && d / 32 <= 32 && c.M <= 128 && t3k::gemm_as_takes(c.M, d)) {
-            const void* any = m->frag(lw.wo, 2, c.M, true);   // o_proj below its tuned row range still pays for itself here
-            if (any != nullptr) { wo_f = any; split_ln2 = true; }
-        }
         {
             t3k::GemmArgs a;
             a.W = lw.wo; a.Wf = wo_f; a.A = c.attn_out; a.M = c.M; a.N = d; a.K = d;
             a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_o;
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
             if (split_ln2) { a.next_act = c.xn; a.next_norm_w = lw.ln2; a.next_ss = c.row_ss; }
+            if (split_ln2 && turbo) { a.resid_mean = c.row_mu; a.row_dot = c.row_mu + t3k::kAsMaxRows; a.row_dot_n = H; a.mean_shift = lw.o_bias_mean; }
             int ks = 1;
             a.ks_out = &ks;
             HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, wdt, st));
@@ -932,7 +979,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
         {
             t3k::GemmArgs a;
             a.W = lw.wgu; a.Wf = gu_f; a.A = c.xn; a.M = c.M; a.N = turbo ? F : 2 * F; a.K = d; a.yact = c.hact;
-            a.bias = lw.b_fc;
+            a.bias = split_ln2 ? lw.b_fc_f : lw.b_fc;   // Turbo: with the split, b_ln arrives as W . b_ln in the bias (Llama: both null)
             if (split_ln2) { a.row_ss = c.row_ss; a.row_ss_tiles = d / 32; a.norm_eps = m->eps; }
             HIPCHK(t3k::launch_gemm(a, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, wdt, st));
         }
@@ -967,6 +1014,7 @@ GemmCtx decode_ctx(Session* s) {
     c.pm = s->pm.as<float>(); c.pl = s->pl.as<float>(); c.pacc = s->pacc.as<float>();
     c.kps = s->kps; c.n_split = s->n_split;
     c.row_ss = s->rowss.as<float>();
+    c.row_mu = s->rowmu;
     return c;
 }
 
@@ -1310,7 +1358,8 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         for (int u = 0; u < n_utt; ++u) items += (size_t)rpu * s0[u];
         const size_t part_rows = std::max<size_t>(s->gemm_mode ? rows : 0, items <= 1024 ? items : 0);
         HIPCHK(s->gpart.alloc(part_rows ? 8 * part_rows * d * 4 : 16));
-        HIPCHK(s->rowss.alloc((size_t)(d / 32 + 1) * t3k::kAsMaxRows * 4));
+        HIPCHK(s->rowss.alloc((size_t)(d / 32 + 2 + 32) * t3k::kAsMaxRows * 4));
+        s->rowmu = s->rowss.as<float>() + (size_t)(d / 32 + 1) * t3k::kAsMaxRows;
     }
     HIPCHK(s->logits.alloc(rows * V * 4));
     HIPCHK(s->rowpos.alloc(rows * 4));

@@ -57,7 +57,9 @@ def main():
     bw = 4 if a.dtype == "f32" else 2
     Lavg = a.s0 + K / 2
     for key, rows in (("sequential", 1), ("batched", a.sentences)):
-        b = P * bw + rows * L * 2 * d * (Lavg + 1) * 4 + rows * V * 4
+        bkv = 2 if (a.dtype == "bf16" and rows > 4) else 4   # the many-row bf16 regime keeps a bf16 cache
+        b = P * bw + rows * L * 2 * d * (Lavg + 1) * bkv + rows * V * 4
+        out[key]["kv_bytes_per_element"] = bkv
         out[key]["hbm_frac_of_8TBs"] = round(b / (out[key]["decode_ms_per_step"] * 1e-3) / 8e12, 4)
     model.close()
     print(json.dumps(out))

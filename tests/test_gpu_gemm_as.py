@@ -151,6 +151,37 @@ def test_split_rms_norm_equals_the_norm_launch(dtype, tol):
         split.close()
 
 
+@pytest.mark.parametrize("dtype,tol", [("bf16", AS_VS_STAGED_TOL), ("f32", F32_AS_VS_STAGED_TOL)])
+def test_split_layer_norm_equals_the_norm_launch(dtype, tol):
+    """Turbo's ln_2 (LayerNorm, R/t3.R:1190-1204) split the same way: attn.c_proj's blocks compute the new row mean as ln_1's
+    row mean + attention row . column means of the weight + mean(bias), write w_ln * (x - mean) and per-tile sums of
+    (x - mean)^2, and c_fc scales its rows and adds its bias with W . b_ln folded in -- against the same kernels with the
+    LayerNorm as a launch (T3MI_NORM_SPLIT=0).  Full-size Turbo, 6 to 128 rows (one row per sentence)."""
+    dims = synth.TURBO_FULL
+    path = synth.ensure_turbo_checkpoint(dims, 4321)
+    old = os.environ.get("T3MI_NORM_SPLIT")
+    os.environ["T3MI_NORM_SPLIT"] = "0"
+    try:
+        plain = cb.load_t3_turbo(path, device=0, dtype=dtype)
+    finally:
+        if old is None:
+            del os.environ["T3MI_NORM_SPLIT"]
+        else:
+            os.environ["T3MI_NORM_SPLIT"] = old
+    split = cb.load_t3_turbo(path, device=0, dtype=dtype)
+    try:
+        for U in (6, 11, 27, 54, 128):
+            embs = [synth.synth_embeds(1, 9 + (u % 5), dims.hidden_size, 900 + u) for u in range(U)]
+            a, forced = _run(plain, embs, 3)
+            b, _ = _run(split, embs, 3, forced)
+            for i in range(4):
+                assert np.isfinite(b[i]).all()
+                assert rel_err(b[i], a[i]) < tol, (dtype, U, i, rel_err(b[i], a[i]))
+    finally:
+        plain.close()
+        split.close()
+
+
 def test_activation_stationary_gemm_is_deterministic():
     """The K slices meet in LDS in a fixed order and the K-split slabs are folded in a fixed order: two sessions over
     the same batch give bit-identical logits."""
