@@ -19,8 +19,9 @@ must equal --gpus or the run exits non-zero; without a launcher the parent proce
 GPU call) starts --gpus fresh rank processes itself.
 
 The N = 1 default run also attaches, under extra keys of the SAME JSON line, the 64-utterance
-bf16 session of configs[2] ("batch64") and the 512-utterance workload of configs[3] on this
-rank count ("cfg4_512utt"), each measured after the headline region.
+bf16 session of configs[2] ("batch64"), the 512-utterance workload of configs[3] on this
+rank count ("cfg4_512utt") and configs[4]'s 8 Turbo sentences batched ("turbo8"), each measured
+after the headline region.
 
 Prefill and weight upload happen before the timed region (inputs resident in HBM); the timed
 region is exactly K decode steps bracketed by barrier + synchronize on both sides.
@@ -55,7 +56,7 @@ def parse(argv=None):
                     help="weight storage type (default f32; bf16 with --total-utterances)")
     ap.add_argument("--cpu-steps", type=int, default=600, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-attach", action="store_true", help="skip the batch64 / cfg4_512utt attachments")
+    ap.add_argument("--no-attach", action="store_true", help="skip the batch64 / cfg4_512utt / turbo8 attachments")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barriers (gloo: rehearsal of the N > 1 path on a box with fewer GPUs "
                          "than ranks; ranks then share devices round-robin)")
@@ -285,6 +286,34 @@ def sharded_workload(rk: Ranks, cb, model, total: int, s0: int, dtype: str, K: i
             "token_checksum": int(sum(int(t.sum()) for t in toks) % (1 << 31))}
 
 
+def turbo_workload(rk: Ranks, cb, synth, sentences: int = 8, s0: int = 407, K: int = 300):
+    """configs[4] (SURVEY §8d cfg 5): Chatterbox-Turbo T3 (GPT-2 medium shapes, synthetic weights), `sentences` sentences of one
+    row each (no CFG pair), prompt 1 + 375 + 30 + 1 rows, K greedy decode steps, batched in one session -- what the
+    reference's tts_chunked does one sentence after the other (R/tts.R:462-474).  scripts/bench_turbo.py has both orders."""
+    dims = synth.TURBO_FULL
+    model = cb.load_t3_turbo(synth.ensure_turbo_checkpoint(dims, 4321), device=rk.local_rank, dtype="bf16")
+    try:
+        embs = [synth.synth_embeds(1, s0, dims.hidden_size, 2000 + u) for u in range(sentences)]
+        tp0 = time.perf_counter()
+        sess = cb.Session(model, embs, max_new_tokens=K + 4, top_p=0.0, mask_stop=True)
+        sess.sync()
+        prefill_ms = (time.perf_counter() - tp0) * 1e3
+        dt, ev_ms = timed_decode(rk, sess, K, 0)
+        sess.end()
+    finally:
+        model.close()
+    d, F, V, L = dims.hidden_size, 4 * dims.hidden_size, dims.speech_vocab, dims.n_layer
+    P = L * (4 * d * d + 2 * d * F + 9 * d + F) + 2 * d + V * d + V          # decode-path parameters incl. biases
+    bkv = 2 if sentences > 4 else 4                                            # many-row bf16 regime: bf16 cache
+    bstep = P * 2 + sentences * L * 2 * d * (s0 + (K - 1) / 2.0 + 1) * bkv + sentences * V * 4
+    us = ev_ms * 1e3 / K
+    return {"workload": f"configs[4]: Turbo T3 (24 x d1024, V{V}), {sentences} sentences batched x (S0={s0}, {K} greedy steps), bf16 weights + "
+                        f"{'bf16' if bkv == 2 else 'fp32'} KV cache, synthetic weights",
+            "tokens_per_s": round(sentences * K / dt, 1), "ms_per_step": round(dt * 1e3 / K, 4), "hip_event_ms_per_step": round(ev_ms / K, 4),
+            "steps": K, "prefill_ms": round(prefill_ms, 1), "bytes_per_step": int(bstep),
+            "GBps": round(bstep / (us * 1e-6) / 1e9, 1), "frac": round(bstep / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def run(args, world, rank, local_rank):
     rk = Ranks(world, rank, local_rank, args.backend)
     torch = rk.torch
@@ -445,6 +474,11 @@ def run(args, world, rank, local_rank):
                 m16.close()
         except Exception as e:   # an attachment must never cost the headline line
             attach["attach_error"] = f"{type(e).__name__}: {e}"
+        if world == 1:
+            try:
+                attach["turbo8"] = turbo_workload(rk, cb, synth)
+            except Exception as e:
+                attach["turbo8_error"] = f"{type(e).__name__}: {e}"
 
     if rank == 0:
         cpu = None
