@@ -21,3 +21,6 @@ SL="python3 scripts/run_session.py --utt 64 --s0 258 --dtype bf16"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/c3L_fetch -o run -- $SL --steps 12 --chunk 12 > $OUT/c3L_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/c3L_write -o run -- $SL --steps 12 --chunk 12 > $OUT/c3L_write.log 2>&1
 python scripts/pmc_traffic.py $OUT/c3L_fetch/run_counter_collection.csv $OUT/c3L_write/run_counter_collection.csv | tee $OUT/c3L_traffic.json
+# Turbo (configs[4]): records and kernel traces of the batched sessions
+cd $GRAFT_REPO_ROOT 2>/dev/null || true
+bash scripts/turbo_trace.sh round
