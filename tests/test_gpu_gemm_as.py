@@ -138,6 +138,7 @@ def test_split_rms_norm_equals_the_norm_launch(dtype, tol):
         else:
             os.environ["T3MI_NORM_SPLIT"] = old
     split = cb.load_t3(path, device=0, dtype=dtype)
+    ran_split = False
     try:
         for U in (3, 11, 27, 64):
             embs = [synth.synth_embeds(2, 9 + (u % 5), dims.hidden_size, 900 + u) for u in range(U)]
@@ -146,6 +147,8 @@ def test_split_rms_norm_equals_the_norm_launch(dtype, tol):
             for i in range(4):
                 assert np.isfinite(b[i]).all()
                 assert rel_err(b[i], a[i]) < tol, (dtype, U, i, rel_err(b[i], a[i]))
+            ran_split = ran_split or any(not np.array_equal(b[i], a[i]) for i in range(4))
+        assert ran_split, "bit-identical logits at every size: the split form did not run"   # (it sums and rounds in another order)
     finally:
         plain.close()
         split.close()
@@ -169,6 +172,7 @@ def test_split_layer_norm_equals_the_norm_launch(dtype, tol):
         else:
             os.environ["T3MI_NORM_SPLIT"] = old
     split = cb.load_t3_turbo(path, device=0, dtype=dtype)
+    ran_split = False
     try:
         for U in (6, 11, 27, 54, 128):
             embs = [synth.synth_embeds(1, 9 + (u % 5), dims.hidden_size, 900 + u) for u in range(U)]
@@ -177,6 +181,49 @@ def test_split_layer_norm_equals_the_norm_launch(dtype, tol):
             for i in range(4):
                 assert np.isfinite(b[i]).all()
                 assert rel_err(b[i], a[i]) < tol, (dtype, U, i, rel_err(b[i], a[i]))
+            ran_split = ran_split or any(not np.array_equal(b[i], a[i]) for i in range(4))
+        assert ran_split, "bit-identical logits at every size: the split form did not run"   # (it sums and rounds in another order)
+    finally:
+        plain.close()
+        split.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("bf16", AS_VS_STAGED_TOL), ("f32", F32_AS_VS_STAGED_TOL)])
+def test_split_layer_norm_with_large_row_means(dtype, tol, tmp_path):
+    """The same comparison on a tiny Turbo model whose statistics make every term of the mean formula large: token embeddings
+    with mean 2 (spread 0.02), attn.c_proj weights with column means 0.01 (as large as their spread) and a c_proj bias with
+    mean 0.3 -- the row mean the split derives (ln_1's mean + attention row . column means + mean(bias)) must centre the rows
+    as well as the LayerNorm launch's own two-pass mean does."""
+    dims = synth.TURBO_TINY
+    w = synth.synth_turbo_weights(dims, 4321)
+    w["speech_emb.weight"] = (w["speech_emb.weight"] + np.float32(2.0)).astype(np.float32)
+    for l in range(dims.n_layer):
+        p = f"tfmr.h.{l}."
+        w[p + "attn.c_proj.weight"] = (w[p + "attn.c_proj.weight"] + np.float32(0.01)).astype(np.float32)
+        w[p + "attn.c_proj.bias"] = (w[p + "attn.c_proj.bias"] + np.float32(0.3)).astype(np.float32)
+    path = synth.write_safetensors(w, str(tmp_path / "turbo_offset.safetensors"))
+    kw = dict(device=0, dtype=dtype, start_speech_token=dims.start_speech_token, stop_speech_token=dims.stop_speech_token)
+    old = os.environ.get("T3MI_NORM_SPLIT")
+    os.environ["T3MI_NORM_SPLIT"] = "0"
+    try:
+        plain = cb.load_t3_turbo(path, **kw)
+    finally:
+        if old is None:
+            del os.environ["T3MI_NORM_SPLIT"]
+        else:
+            os.environ["T3MI_NORM_SPLIT"] = old
+    split = cb.load_t3_turbo(path, **kw)
+    ran_split = False
+    try:
+        for U in (7, 20, 33, 100):
+            embs = [synth.synth_embeds(1, 9 + (u % 5), dims.hidden_size, 900 + u) + np.float32(1.5) for u in range(U)]
+            a, forced = _run(plain, embs, 3)
+            b, _ = _run(split, embs, 3, forced)
+            for i in range(4):
+                assert np.isfinite(b[i]).all()
+                assert rel_err(b[i], a[i]) < tol, (dtype, U, i, rel_err(b[i], a[i]))
+            ran_split = ran_split or any(not np.array_equal(b[i], a[i]) for i in range(4))
+        assert ran_split, "bit-identical logits at every size: the split form did not run"   # (it sums and rounds in another order)
     finally:
         plain.close()
         split.close()
