@@ -90,6 +90,9 @@ SYMBOLS = {
     "t3mi_session_status": (C.c_int, [_H, _IP, _IP]),
     "t3mi_session_tokens": (C.c_int, [_H, C.c_int, _IP, C.c_int32, _IP]),
     "t3mi_session_logits": (C.c_int, [_H, _FP]),
+    "t3mi_session_set_logits": (C.c_int, [_H, _FP]),
+    "t3mi_session_keep_filtered": (C.c_int, [_H]),
+    "t3mi_session_filtered_logits": (C.c_int, [_H, C.c_int, _FP]),
     "t3mi_session_dist": (C.c_int, [_H, C.c_int, _IP, _FP, C.c_int32, _IP]),
     "t3mi_session_drawn": (C.c_int, [_H, _IP]),
     "t3mi_session_profile_step": (C.c_int, [_H, C.POINTER(KStat), C.c_int, C.POINTER(C.c_int)]),

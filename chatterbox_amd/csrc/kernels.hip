@@ -821,6 +821,7 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
         }
         if (a.temperature != 1.0f && !(turbo && !(a.temperature > 0.f))) l = __fdiv_rn(l, a.temperature);
         lg[v] = l;
+        if (a.filt != nullptr) a.filt[(size_t)u * V + v] = l;   // parity hook (t3mi_session_filtered_logits)
         lmax = fmaxf(lmax, l);
     }
     lmax = block_reduce_max(lmax, scratch);

@@ -164,6 +164,7 @@ struct SamplerArgs {
     int* dist_n = nullptr;
     int* drawn = nullptr;         // [n_utt] token drawn before teacher forcing (debug)
     int dist_cap = 0;
+    float* filt = nullptr;        // [n_utt, V] debug (may be nullptr): the logits row after CFG, penalty and temperature
 };
 
 size_t sampler_lds_bytes(int V);

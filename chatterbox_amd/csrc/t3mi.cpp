@@ -125,6 +125,7 @@ struct Session {
     std::vector<int32_t> s0;
     DevBuf kc, vc, x, qbuf, pm, pl, pacc, hbuf, logits, rope_cur, rowpos, start, emb_rows, emb_data, seen, tokens, n_tokens,
         done, s0_dev, forced, dist_ids, dist_probs, dist_n, drawn;
+    DevBuf filt;                // [n_utt][V] logits after CFG / penalty / temperature (t3mi_session_keep_filtered), else empty
     int n_forced = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
@@ -1075,6 +1076,7 @@ int run_sampler(t3mi_model* m, Session* s, StepTimer* tm) {
     a.dist_ids = s->dist_ids.as<int>(); a.dist_probs = s->dist_probs.as<float>(); a.dist_n = s->dist_n.as<int>();
     a.drawn = s->drawn.as<int>();
     a.dist_cap = m->V;
+    a.filt = s->filt.p ? s->filt.as<float>() : nullptr;
     HIPCHK(t3k::launch_sampler(a, m->stream));
     if (tm) tm->mark(K_SAMPLER);
     return T3MI_OK;
@@ -1609,6 +1611,42 @@ int t3mi_session_logits(t3mi_model* m, float* out) {
     HIPCHK(hipSetDevice(m->device));
     HIPCHK(hipStreamSynchronize(m->stream));
     HIPCHK(hipMemcpy(out, s->logits.p, (size_t)s->rows * m->V * 4, hipMemcpyDeviceToHost));
+    return T3MI_OK;
+}
+
+int t3mi_session_set_logits(t3mi_model* m, const float* logits) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    if (!logits) return fail(T3MI_ERR_ARG, "t3mi_session_set_logits: null logits");
+    Session* s = m->sess.get();
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));   // the head launch that wrote the pending logits
+    HIPCHK(hipMemcpy(s->logits.p, logits, (size_t)s->rows * m->V * 4, hipMemcpyHostToDevice));
+    return T3MI_OK;
+}
+
+int t3mi_session_keep_filtered(t3mi_model* m) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    Session* s = m->sess.get();
+    if (s->gexec) return fail(T3MI_ERR_STATE, "t3mi_session_keep_filtered must precede the first decode call");
+    HIPCHK(hipSetDevice(m->device));
+    if (!s->filt.p) {
+        HIPCHK(s->filt.alloc((size_t)s->n_utt * m->V * 4));
+        HIPCHK(hipMemset(s->filt.p, 0, s->filt.bytes));
+    }
+    return T3MI_OK;
+}
+
+int t3mi_session_filtered_logits(t3mi_model* m, int utt, float* out) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    Session* s = m->sess.get();
+    if (utt < 0 || utt >= s->n_utt || !out) return fail(T3MI_ERR_ARG, "t3mi_session_filtered_logits: bad argument");
+    if (!s->filt.p) return fail(T3MI_ERR_STATE, "t3mi_session_filtered_logits: call t3mi_session_keep_filtered before the first decode");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(out, s->filt.as<float>() + (size_t)utt * m->V, (size_t)m->V * 4, hipMemcpyDeviceToHost));
     return T3MI_OK;
 }
 

@@ -460,6 +460,23 @@ class Session:
         _lib.check(self.model._lib.t3mi_session_logits(self.model._h, out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
+    def set_logits(self, logits) -> None:
+        """Replace the pending logits [rows, vocab] (parity hook: the reference's recorded logits go through the
+        device sampling tail, scripts/debug_t3_step.R:108-214)."""
+        lg = np.ascontiguousarray(logits, dtype=np.float32)
+        if lg.shape != (self.n_utt * self.rpu, self.model.vocab):
+            raise ValueError(f"logits must be [{self.n_utt * self.rpu}, {self.model.vocab}], got {lg.shape}")
+        _lib.check(self.model._lib.t3mi_session_set_logits(self.model._h, lg.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def keep_filtered(self) -> None:
+        _lib.check(self.model._lib.t3mi_session_keep_filtered(self.model._h))
+
+    def filtered_logits(self, utt: int = 0) -> np.ndarray:
+        """The logits row after CFG, repetition penalty and temperature at the most recent step (R/t3.R:518-537)."""
+        out = np.zeros(self.model.vocab, dtype=np.float32)
+        _lib.check(self.model._lib.t3mi_session_filtered_logits(self.model._h, int(utt), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
     def dist(self, utt: int = 0):
         V = self.model.vocab
         ids = np.zeros(V, dtype=np.int32)

@@ -210,6 +210,17 @@ int t3mi_session_status(t3mi_model* m, int32_t* n_tokens, int32_t* done);
 int t3mi_session_tokens(t3mi_model* m, int utt, int32_t* out, int32_t cap, int32_t* n_out);
 /* Raw speech-head logits [rows_total, vocab] of the most recent step (parity hook). */
 int t3mi_session_logits(t3mi_model* m, float* out);
+/* Overwrite the pending logits [rows_total, vocab] (the ones the NEXT decode step's sampling tail will read) with a host
+ * array.  Parity hook with no counterpart in the reference's API: it is how a test hands the reference's own recorded
+ * logits (outputs/t3_debug.safetensors `raw_logits_step0`, replayed by scripts/debug_t3_step.R:108-214) to the device
+ * sampling tail without the weights that produced them. */
+int t3mi_session_set_logits(t3mi_model* m, const float* logits);
+/* Keep, from the next decode step on, every utterance's logits row after CFG combine, repetition penalty and temperature
+ * (R/t3.R:518-537; the values scripts/debug_t3_step.R:119-151 compares with `logits_after_cfg` / `logits_after_temp`).
+ * Call between session_begin and the first session_decode; costs one [n_utt, vocab] fp32 buffer and a store per logit. */
+int t3mi_session_keep_filtered(t3mi_model* m);
+/* out[vocab] = that row for utterance `utt` at the most recent step (T3MI_ERR_STATE without t3mi_session_keep_filtered). */
+int t3mi_session_filtered_logits(t3mi_model* m, int utt, float* out);
 /* Final filtered distribution of utterance `utt` at the most recent step: ids in descending
  * probability, their renormalised probabilities; *n = support size (parity hook). */
 int t3mi_session_dist(t3mi_model* m, int utt, int32_t* ids, float* probs, int32_t cap, int32_t* n);

@@ -49,6 +49,15 @@ def test_full_size_configs3_shard_shapes(U):
                 s.decode(1)
                 ref.append(s.logits())
             forced = np.array([s.tokens(u)[:n] for u in range(U)])
+        # the fp32 batch is the reference of the bf16 one below, so it is itself checked against something outside it: the
+        # last utterance (highest cache addresses) and a middle one ALONE, on the <= 4-row GEMV path that the oracle tests
+        # of test_gpu_parity.py pin at this size -- other kernels (GEMV vs MFMA GEMM), other cache rows, same fp32 arithmetic
+        for u in (U - 1, U // 3):
+            with cb.Session(m32, [embs[u]], max_new_tokens=n + 1, top_p=0.0, mask_stop=True, forced=forced[u:u + 1]) as s:
+                for i in range(n + 1):
+                    assert rel_err(ref[i][2 * u:2 * u + 2], s.logits()) < LOGIT_TOL, f"fp32 utterance {u} alone, step {i}"
+                    if i < n:
+                        s.decode(1)
     finally:
         m32.close()
     m16 = cb.load_t3(path, device=0, dtype="bf16")
@@ -122,7 +131,8 @@ def test_full_size_bf16_long_context_128_rows():
         print(f"bf16 vs fp32 at 128 rows: logit rel err by step {errs}; greedy agreement {agree.mean():.3f}, "
               f"first divergence step min / median {min(first_div)} / {int(np.median(first_div))}")
         assert max(errs.values()) < BF16_LOGIT_TOL, errs
-        assert agree.mean() > 0.5
+        # measured 95.7 % (round 2); the synthetic model's flat distributions put ~4 % of the arg-maxes inside the bf16 error
+        assert agree.mean() > 0.9
     finally:
         m16.close()
 
@@ -323,6 +333,19 @@ def test_tts_chunked_batch_equals_serial():
                 [t for t in raw["speech_tokens"][i] if t < dims.start_speech_token]
         one = cb.t3_inference_batch(model, [cond] * 4, [tokenize(s) for s in got["sentences"]], **kw)
         assert all(list(cb.drop_invalid_tokens(x)) == list(y) for x, y in zip(one, got["speech_tokens"]))
+        # Greedy (top_p = 0, fp32): no RNG and no near-tie tolerance -- EVERY sentence's whole stream, batched (8 rows: MFMA GEMM
+        # kernels) and serial (2 rows: GEMV kernels), equals the oracle's t3_inference on the oracle's own prompt, token for token
+        gk = dict(max_new_tokens=16, top_p=0.0, cfg_weight=0.5, temperature=0.8)
+        gb = cb.tts_chunked(model, text, cond, tokenize, drop_invalid=False, **gk)
+        gs = cb.tts_chunked(model, text, cond, tokenize, batched=False, drop_invalid=False, **gk)
+        w = synth.synth_llama_weights(dims, 4321, 8.0)
+        om = oracle_model(dims, 4321, head_scale=8.0)
+        for i, sent in enumerate(got["sentences"]):
+            pe, _ = O.prepare_input_embeds(w, cond.speaker_emb, cond.cond_prompt_speech_tokens, 0.5, tokenize(sent), 0.5,
+                                           dims.start_speech_token)
+            want = O.t3_inference(om, pe, O.SampleParams(max_new_tokens=16, top_p=0.0)).tokens
+            assert list(gb["speech_tokens"][i]) == want, f"batched, sentence {i}"
+            assert list(gs["speech_tokens"][i]) == want, f"serial, sentence {i}"
     finally:
         model.close()
 
