@@ -60,6 +60,9 @@ def parse(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barriers (gloo: rehearsal of the N > 1 path on a box with fewer GPUs "
                          "than ranks; ranks then share devices round-robin)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group even with ONE rank, so that the N > 1 code path (init_process_group, "
+                         "barrier, MAX all-reduce on a device tensor, all_gather_object) runs on a one-GPU box")
     return ap.parse_args(argv)
 
 
@@ -96,13 +99,31 @@ def spawn_ranks(gpus: int, argv) -> int:
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
+    # a rank that dies leaves the others waiting at a barrier: as soon as one exits non-zero, end the rest (by PID) so
+    # the whole run fails instead of hanging until the collective's own timeout
+    import threading
+    buf = []
+    rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    rc = 0
+    live = set(range(gpus))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write(f"bench.py: rank {r} exited with status {code}; stopping the other ranks\n")
+                for q in sorted(live):
+                    procs[q].terminate()
+        if live:
+            time.sleep(0.2)
+    rd.join(timeout=10)
+    if rc == 0 and buf:
+        sys.stdout.write(buf[0].decode())
+        sys.stdout.flush()
     return rc
 
 
@@ -175,7 +196,7 @@ def cpu_baseline(n_steps: int, s0: int, emb: np.ndarray):
 class Ranks:
     """The process group as this run sees it: barrier, max-over-ranks, and the module for shard.decode_sharded."""
 
-    def __init__(self, world, rank, local_rank, backend):
+    def __init__(self, world, rank, local_rank, backend, force_dist=False):
         import torch
         self.torch, self.world, self.rank, self.backend = torch, world, rank, backend
         self.dist = None
@@ -184,9 +205,16 @@ class Ranks:
         self.gpu = torch.cuda.is_available()      # False only in the CPU tests of this file's host logic
         if self.gpu:
             torch.cuda.set_device(self.local_rank)
-        if world > 1:
+        if world > 1 or force_dist:
             import torch.distributed as dist_mod
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:      # --force-dist without a launcher: a one-rank group of our own
+                sk = socket.socket()
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+                sk.close()
+            os.environ.setdefault("RANK", str(rank))
+            os.environ.setdefault("WORLD_SIZE", str(world))
             if backend == "nccl":
                 dist_mod.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
             else:
@@ -315,7 +343,7 @@ def turbo_workload(rk: Ranks, cb, synth, sentences: int = 8, s0: int = 407, K: i
 
 
 def run(args, world, rank, local_rank):
-    rk = Ranks(world, rank, local_rank, args.backend)
+    rk = Ranks(world, rank, local_rank, args.backend, args.force_dist)
     torch = rk.torch
     import chatterbox_amd as cb
     from chatterbox_amd import synth
@@ -350,7 +378,8 @@ def run(args, world, rank, local_rank):
                                        f"(u -> floor(u*G/U)), greedy top_p=0, S0={s0}, {K} timed steps, Llama-520M synthetic weights, {r['dtype']}",
                            "total_utterances": args.total_utterances, "rows_on_busiest_rank": r["rows_on_busiest_rank"], "s0": s0,
                            "parallelism": f"utterance-sharded x{world} (no collectives; token vectors gathered by shard.decode_sharded)"},
-                "world_size_observed": world, "hip_event_ms_per_step": r["hip_event_ms_per_step"], "prefill_ms": r["prefill_ms"],
+                "world_size_observed": world, "backend": args.backend if rk.dist is not None else None,
+                "hip_event_ms_per_step": r["hip_event_ms_per_step"], "prefill_ms": r["prefill_ms"],
                 "token_checksum": r["token_checksum"],
                 "roofline": {"bound": "hbm", "kernel": "decode_step of the busiest rank (replayed HIP graph)", "achieved": r["GBps_per_gpu"],
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac"], "traffic": None,
@@ -503,6 +532,7 @@ def run(args, world, rank, local_rank):
                        "utterances_per_gpu": U, "rows_per_gpu": rows, "s0": s0,
                        "parallelism": f"utterance-sharded x{world} (no collectives)"},
             "world_size_observed": world,
+            "backend": args.backend if rk.dist is not None else None,      # the process group the barriers ran on (None: one rank, no group)
             "hip_event_ms_per_step": round(ev_ms / K, 5),
             "prefill_ms": round(prefill_ms, 3),   # rank 0: session set-up + prefill of its utterances (not in `value`)
             "roofline": roof,

@@ -18,6 +18,16 @@
 #include <cstdlib>
 #include <type_traits>
 
+// In-kernel clock stamps of the GEMM kernels (scripts/micro/gemm_micro.cpp reads them through GemmArgs::dbg): diagnostic
+// builds only (make stamps / -DT3K_STAMPS); the shipped kernels carry neither the test nor the stores.
+#ifdef T3K_STAMPS
+#define T3K_DBG_DECL(cond, blk) unsigned long long* dbg = (cond) ? a.dbg + 4 * (size_t)(blk) : nullptr
+#define T3K_DBG_STAMP(i) do { if (dbg) dbg[i] = wall_clock64(); } while (0)
+#else
+#define T3K_DBG_DECL(cond, blk) do { } while (0)
+#define T3K_DBG_STAMP(i) do { } while (0)
+#endif
+
 namespace t3k {
 
 namespace {
@@ -747,9 +757,8 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     // below folds away -- with run-time conditions around the ring refills the compiler waits for vmcnt(0) in every
     // step (it must cover the path on which nothing was issued) and the register rings hide nothing.
     const int S = SC > 0 ? SC : (K / KC) / (int)gridDim.z;
-    unsigned long long* dbg = a.dbg != nullptr && tid == 0
-                                  ? a.dbg + 4 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
-    if (dbg) dbg[0] = wall_clock64();
+    T3K_DBG_DECL(a.dbg != nullptr && tid == 0, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    T3K_DBG_STAMP(0);
     const int kbeg = kz * S * KC;
     const T* Wp = static_cast<const T*>(a.W);
     const T* Ap = static_cast<const T*>(a.A);
@@ -798,7 +807,7 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
     *reinterpret_cast<uint4*>(&tl[soff + kARows * LD]) = rw[0];
     if (kDW < S) rw[0] = *reinterpret_cast<const uint4*>(src[4] + (size_t)kDW * KC);
     __syncthreads();
-    if (dbg) dbg[1] = wall_clock64();
+    T3K_DBG_STAMP(1);
     // 24 = lcm(kDW, kDA): ring slots are compile-time indices inside the unrolled body
     for (int s0 = 0; s0 < S; s0 += 24) {
 #pragma unroll
@@ -859,7 +868,7 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
             }
         }
     }
-    if (dbg) dbg[2] = wall_clock64();
+    T3K_DBG_STAMP(2);
     if (!live) return;
     // accumulator layout: row = g*4 + r of the wave's 16 rows, column nl of the sub-tile
     {
@@ -874,7 +883,7 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(GemmArgs a) {
         for (int r = 0; r < 4; ++r)
             rows_epilogue<EPI, T>(a, tile, nl, m0 + wave * 16 + g * 4 + r, acc0[r], acc1[r], kz, gridDim.z > 1, er[r], ec, cs[r]);
     }
-    if (dbg) dbg[3] = wall_clock64();
+    T3K_DBG_STAMP(3);
 }
 
 // ---- bf16 GEMM for more than 128 rows (512 utterances per GPU, the prompt prefill of a batch) --------------------
@@ -909,9 +918,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a, int tiles32,
     const int m0 = chunk * BM, kz = blockIdx.y;
     const int K = a.K;
     const int S = (K / 64) / (int)gridDim.y;             // 64-k steps of this block
-    unsigned long long* dbg = a.dbg != nullptr && tid == 0 && blockIdx.x + gridDim.x * blockIdx.y < 4096
-                                  ? a.dbg + 4 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y) : nullptr;
-    if (dbg) dbg[0] = wall_clock64();
+    T3K_DBG_DECL(a.dbg != nullptr && tid == 0 && blockIdx.x + gridDim.x * blockIdx.y < 4096, blockIdx.x + gridDim.x * blockIdx.y);
+    T3K_DBG_STAMP(0);
     const int kbeg = kz * S * 64;
     const T* Wp = static_cast<const T*>(a.W);
     const T* Ap = static_cast<const T*>(a.A);
@@ -966,7 +974,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a, int tiles32,
         for (int p = 0; p < PW; ++p) rw[0][p] = *reinterpret_cast<const uint4*>(srcW[p] + (size_t)kWW * 64);
     }
     __syncthreads();
-    if (dbg) dbg[1] = wall_clock64();
+    T3K_DBG_STAMP(1);
     // One step.  U = s % 4 comes as a type so that the ring slots are literal indices (the rings stay in registers).
     // CK = false is the steady state: no branches at all -- the tile of step s + 1 is always staged (after the last
     // step it lands in a buffer nobody reads) and the refill loads clamp their step to S - 1 -- so that the compiler
@@ -1023,7 +1031,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a, int tiles32,
     step(integral_constant<int, 0>{}, std::true_type{}, s0);
     step(integral_constant<int, 1>{}, std::true_type{}, s0 + 1);
     step(integral_constant<int, 2>{}, std::true_type{}, s0 + 2);
-    if (dbg) dbg[2] = wall_clock64();
+    T3K_DBG_STAMP(2);
     // wave (wm, wn): rows m0 + 16 (MT wm + i) + 4 g + r; sub-tiles 2 tt / 2 tt + 1 are the partner halves of 32-feature
     // tile blk NT + wn NT/2 + tt
     {
@@ -1055,7 +1063,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a, int tiles32,
                                               gridDim.y > 1, er[i][r], ec[tt], cs[i][r][tt]);
                 }
     }
-    if (dbg) dbg[3] = wall_clock64();
+    T3K_DBG_STAMP(3);
 }
 
 // ---- bf16 many-row GEMM, third generation: activation-stationary, for <= 128 rows --------------------------------
@@ -1120,9 +1128,8 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     const int sub = wave % NSUB, kw = wave / NSUB;
     const int m0 = blockIdx.y * MC, kz = blockIdx.z;
     const int K = a.K;
-    unsigned long long* dbg = a.dbg != nullptr && tid == 0
-                                  ? a.dbg + 4 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : nullptr;
-    if (dbg) dbg[0] = wall_clock64();
+    T3K_DBG_DECL(a.dbg != nullptr && tid == 0, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    T3K_DBG_STAMP(0);
     // Every global load of the kernel is issued here, activations first: they come from L2 and are consumed first, and
     // loads complete in order.  Phase q of the activation rows = k PHK q .. PHK q + PHK - 1 of the block's range: 32 pieces
     // of 16 B per row, piece tid + 512 i -> row (tid + 512 i) / 32 (32 consecutive threads fetch one 512-byte run).
@@ -1177,7 +1184,7 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) *reinterpret_cast<u32x4*>(sdst + i * 16 * LDA) = va[i];
     __syncthreads();
-    if (dbg) dbg[1] = wall_clock64();
+    T3K_DBG_STAMP(1);
     // straight-line code (rows past M are copies of row M - 1 and are dropped by the epilogue): no branch may sit between
     // the fragment reads and the MFMAs, or every read is waited for on its own
     f32x4 acc[NT];
@@ -1223,7 +1230,7 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     phase(std::integral_constant<int, 5>{});
     phase(std::integral_constant<int, 6>{});
     phase(std::integral_constant<int, 7>{});
-    if (dbg) dbg[2] = wall_clock64();
+    T3K_DBG_STAMP(2);
     if constexpr (NRM == 1) {   // 16 lanes per row add their partial sums in a fixed butterfly order
         float sv = ssa + ssb;
 #pragma unroll
@@ -1309,7 +1316,7 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
                     if (c == 0) a.next_ss[(size_t)tile_[i] * a.M + mi_[i]] = sq;
                 }
             }
-            if (dbg) dbg[3] = wall_clock64();
+            T3K_DBG_STAMP(3);
             return;
         }
     }
@@ -1318,7 +1325,7 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i)
         if (ok_[i]) rows_epilogue<EPI, T>(a, tile_[i], c, mi_[i], v0[i], v1[i], kz, gridDim.z > 1, er[i], ec[i], cs[i]);
-    if (dbg) dbg[3] = wall_clock64();
+    T3K_DBG_STAMP(3);
 }
 
 // y[m][i] = resid[m][i] + bias[i] + sum_s part[s][m][i], s ascending (the K-split of gemm_rows_kernel).

@@ -119,7 +119,7 @@ struct GemmArgs {
     size_t part_floats = 0;
     int* ks_out = nullptr;        // host: receives the K-split factor; with it set a residual GEMM in place (y == resid)
                                   // leaves the fold of its partial slabs to the caller (launch_*norm_rows / launch_fold_partials)
-    unsigned long long* dbg = nullptr;  // diagnostic (scripts/micro/gemm_micro.cpp): [block][4] clock stamps, or nullptr
+    unsigned long long* dbg = nullptr;  // diagnostic builds (-DT3K_STAMPS; scripts/micro/gemm_micro.cpp): [block][4] clock stamps; ignored otherwise
 };
 
 struct EmbedArgs {                // token-by-token prefill input (R/t3.R:494, :505)

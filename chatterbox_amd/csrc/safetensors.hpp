@@ -42,6 +42,7 @@ public:
     const StTensor* find(const std::string& name) const;
     const std::map<std::string, StTensor>& tensors() const { return tensors_; }
     size_t file_size() const { return map_len_; }
+    const uint8_t* base() const { return static_cast<const uint8_t*>(map_); }   // the mapped file (nullptr before open)
     int64_t mtime_ns() const { return mtime_ns_; }
 
     // Convert tensor `t` (F32/F16/BF16) to float32 into dst[numel].

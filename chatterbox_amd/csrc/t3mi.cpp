@@ -41,7 +41,9 @@ namespace {
 thread_local std::string g_err = "";
 
 constexpr int kMaxDevices = 64;
-void* g_static_scratch[kMaxDevices] = {};   // device address of `scratch` on each GPU, filled by t3mi_open
+// device address of `scratch` on each GPU, filled by t3mi_open.  Not locked: the library's contract is one handle per thread
+// (include/t3mi.h), and two threads opening handles on the same device at once would both store the same address here.
+void* g_static_scratch[kMaxDevices] = {};
 
 // with `device` current: the address of this GPU's copy of `scratch` (looked up once per device)
 hipError_t static_scratch(int device, void** out) {
@@ -363,9 +365,10 @@ struct CacheHeader {
     uint32_t version, variant, n_layers, d, F, V;
     uint64_t src_size;
     int64_t src_mtime_ns;
+    uint64_t src_fingerprint;   // checksum of the checkpoint's JSON header and of its first and last MiB of tensor data
     uint64_t payload_bytes, checksum;
 };
-constexpr uint32_t kCacheVersion = 1;
+constexpr uint32_t kCacheVersion = 2;
 
 // four independent multiply-xor lanes over 32-byte groups (a single chain is latency-bound at ~1 GB/s; this runs at
 // memory speed), folded at the end; every byte and its position enter the result
@@ -505,6 +508,25 @@ struct Uploader {
     }
 };
 
+// A fine-tune of the same architecture copied over the checkpoint with its mtime preserved has the size, mtime and dims of
+// the original: the header also carries a content fingerprint -- the safetensors JSON header (names, shapes, offsets) plus
+// the first and the last MiB of the file (tensor data), a few milliseconds to compute.
+uint64_t source_fingerprint(const t3mi::SafeTensorsFile& st) {
+    const uint8_t* base = st.base();
+    const size_t n = st.file_size();
+    if (!base || n == 0) return 0;
+    const size_t mib = (size_t)1 << 20;
+    uint64_t hl = 0;
+    if (n >= 8) std::memcpy(&hl, base, 8);
+    const size_t head = (size_t)std::min<uint64_t>((uint64_t)n, 8 + hl + mib);   // length word + JSON header + first MiB of data
+    uint64_t f = payload_checksum(base, head);
+    if (n > head) {
+        const size_t tail = std::min(mib, n - head);
+        f ^= payload_checksum(base + (n - tail), tail) * 0x9E3779B97F4A7C15ULL;
+    }
+    return f;
+}
+
 CacheHeader cache_header(const t3mi_model* m, const t3mi::SafeTensorsFile& st, size_t payload) {
     CacheHeader h;
     std::memset(&h, 0, sizeof(h));
@@ -517,6 +539,7 @@ CacheHeader cache_header(const t3mi_model* m, const t3mi::SafeTensorsFile& st, s
     h.V = (uint32_t)m->V;
     h.src_size = (uint64_t)st.file_size();
     h.src_mtime_ns = st.mtime_ns();
+    h.src_fingerprint = source_fingerprint(st);
     h.payload_bytes = (uint64_t)payload;
     return h;
 }
@@ -1922,6 +1945,17 @@ int t3mi_prepare_input_embeds_static(t3mi_model* m, const t3mi_cond* cond, const
     int rc = t3mi::prompt_shape(m->prompt, env, pc, n_text, cfg_weight, &rows, &s0, &lc, err);
     if (rc) return fail(rc, err);
     if (cap_floats < (size_t)rows * s0 * m->d) return fail(T3MI_ERR_ARG, "t3mi_prepare_input_embeds_static: output buffer too small");
+    {
+        // the sibling entry point takes a HOST pointer in this slot: a host address here would fault the GPU inside a kernel, so
+        // it is refused up front (a query, no allocation)
+        hipPointerAttribute_t at;
+        std::memset(&at, 0, sizeof(at));
+        const hipError_t pe = hipPointerGetAttributes(&at, out_device);
+        if (pe != hipSuccess || at.type != hipMemoryTypeDevice || at.device != m->device) {
+            (void)hipGetLastError();
+            return fail(T3MI_ERR_ARG, "t3mi_prepare_input_embeds_static: out_device must be device memory on the model's GPU");
+        }
+    }
     size_t need_rows = 0, need_ids = 0;
     t3mi::prompt_scratch_need(m->prompt, env, pc, n_text, &need_rows, &need_ids);
     if (need_rows > kStaticRowsFloats || need_ids > kStaticIds || (size_t)pc.n_speaker > kStaticSpk)

@@ -33,7 +33,7 @@ def decode_sharded(decode_fn: Callable[[Sequence[int]], List[np.ndarray]], n_utt
     if len(outs) != len(mine):
         raise RuntimeError("decode_fn returned the wrong number of utterances")
     local = [(u, np.asarray(t, dtype=np.int64)) for u, t in zip(mine, outs)]
-    if dist is None or world == 1:
+    if dist is None:      # no process group (a single process); with a group the gather runs even for one rank
         gathered = [local]
     else:
         gathered = [None] * world
@@ -60,6 +60,12 @@ def t3_inference_sharded(model, prompts: Sequence, text_tokens_list=None, dist=N
 
     n_utt = len(prompts)
     fn = t3.t3_inference_turbo_batch if turbo else t3.t3_inference_batch
+    if kw.get("seed") is None:
+        # no seed given: rank 0 draws one (t3._seed) and every rank uses it, so the streams (seed, u) are those of one call
+        box = [t3._seed(None) if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(box, src=0)
+        kw["seed"] = box[0]
 
     def decode(mine):
         tt = None if text_tokens_list is None else [text_tokens_list[u] for u in mine]

@@ -91,6 +91,13 @@ def load_t3_turbo(path: str, device: int = 0, dtype: str = "f32", **kw) -> T3Mod
     return T3Model(path, device, dtype, variant=_lib.VARIANT_TURBO, **kw)
 
 
+def _seed(seed) -> int:
+    """Seed of the library's counter RNG.  None = drawn from numpy's global generator, so `np.random.seed()` governs
+    sampled output and repeated calls differ -- the reference draws from torch's global generator (R/t3.R:566) and
+    behaves the same way under torch_manual_seed(); an int = that reproducible stream."""
+    return int(np.random.randint(0, 2**31 - 1)) if seed is None else int(seed)
+
+
 def _params(model: T3Model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
             sampler, max_cache_len=0, seed=0, mask_stop=False, top_k=0, first_utterance_id=0, drop_invalid=None) -> _lib.Params:
     p = _lib.Params()
@@ -107,7 +114,7 @@ def _params(model: T3Model, max_new_tokens, temperature, cfg_weight, top_p, min_
     p.top_k = int(top_k)
     p.max_cache_len = int(max_cache_len)
     p.mask_stop = 1 if mask_stop else 0
-    p.seed = int(seed)
+    p.seed = _seed(seed)
     p.first_utterance_id = int(first_utterance_id)
     # drop_invalid: True = SPEECH_VOCAB_SIZE (6561, R/s3tokenizer.R:7), an int = that limit, None / False = raw stream
     p.drop_invalid_from = 0 if not drop_invalid else (SPEECH_VOCAB_SIZE if drop_invalid is True else int(drop_invalid))
@@ -196,7 +203,7 @@ def _as_embeds(model: T3Model, embeds, cfg_weight: float) -> np.ndarray:
 
 def t3_inference(model: T3Model, cond, text_tokens=None, max_new_tokens: int = 1000, temperature: float = 0.8,
                  cfg_weight: float = 0.5, top_p: float = 0.95, min_p: float = 0.05,
-                 repetition_penalty: float = 1.2, seed: int = 0) -> np.ndarray:
+                 repetition_penalty: float = 1.2, seed: Optional[int] = None) -> np.ndarray:
     """R/t3.R:461-605.  Returns 0-indexed speech tokens, INCLUDING the stop token if it
     was sampled (Q14).  `top_p = 0` is the deterministic (greedy) mode (Q6).
     `cond` is a T3Cond (then `text_tokens` are the text ids, as in the reference) or a prompt
@@ -220,7 +227,7 @@ def t3_inference(model: T3Model, cond, text_tokens=None, max_new_tokens: int = 1
 
 def t3_inference_cpp(model: T3Model, cond, text_tokens=None, max_new_tokens: int = 1000, temperature: float = 0.8,
                      cfg_weight: float = 0.5, top_p: float = 0.95, min_p: float = 0.05,
-                     repetition_penalty: float = 1.2, max_cache_len: int = 350, seed: int = 0) -> np.ndarray:
+                     repetition_penalty: float = 1.2, max_cache_len: int = 350, seed: Optional[int] = None) -> np.ndarray:
     """R/t3.R:932-1050 (backend = "cpp"): 350-slot cache, cpp sampling rule (Q3/Q4),
     result stripped at the first stop token (R/t3.R:1039-1045).  Same two call forms as t3_inference."""
     p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
@@ -246,7 +253,7 @@ def t3_inference_cpp(model: T3Model, cond, text_tokens=None, max_new_tokens: int
 
 def t3_inference_traced(model: T3Model, cond, text_tokens=None, max_new_tokens: int = 1000, temperature: float = 0.8,
                         cfg_weight: float = 0.5, top_p: float = 0.95, min_p: float = 0.05,
-                        repetition_penalty: float = 1.2, max_cache_len: int = 350, seed: int = 0) -> np.ndarray:
+                        repetition_penalty: float = 1.2, max_cache_len: int = 350, seed: Optional[int] = None) -> np.ndarray:
     """R/t3.R:685-871 (`traced = TRUE`): the arithmetic and sampling rule of t3_inference on a fixed
     cache of `max_cache_len` slots; generation is limited to `max_cache_len - cond_len - 1` tokens
     (R/t3.R:753) without a warning, and the stop token stays in the result.  There is nothing to
@@ -275,7 +282,7 @@ def t3_inference_traced(model: T3Model, cond, text_tokens=None, max_new_tokens: 
 def t3_inference_batch(model: T3Model, embeds_list: Sequence, text_tokens_list: Optional[Sequence] = None,
                        max_new_tokens: int = 1000,
                        temperature: float = 0.8, cfg_weight: float = 0.5, top_p: float = 0.95,
-                       min_p: float = 0.05, repetition_penalty: float = 1.2, seed: int = 0,
+                       min_p: float = 0.05, repetition_penalty: float = 1.2, seed: Optional[int] = None,
                        mask_stop: bool = False, first_utterance_id: int = 0, drop_invalid=None) -> List[np.ndarray]:
     """Independent utterances decoded together (the batch axis tts_chunked leaves serial,
     R/tts.R:462-474).  Same per-utterance semantics as t3_inference.  Utterance u of the call draws from the
@@ -301,7 +308,7 @@ def t3_inference_batch(model: T3Model, embeds_list: Sequence, text_tokens_list: 
 def t3_inference_turbo_batch(model: T3Model, embeds_list: Sequence, text_tokens_list: Optional[Sequence] = None,
                              max_new_tokens: int = 1000,
                              temperature: float = 0.8, top_k: int = 1000, top_p: float = 0.95,
-                             repetition_penalty: float = 1.2, seed: int = 0, mask_stop: bool = False,
+                             repetition_penalty: float = 1.2, seed: Optional[int] = None, mask_stop: bool = False,
                              keep_stop: bool = False, first_utterance_id: int = 0, drop_invalid=None) -> List[np.ndarray]:
     """Independent Turbo utterances decoded together; per-utterance semantics of t3_inference_turbo."""
     if model.variant != _lib.VARIANT_TURBO:
@@ -333,7 +340,7 @@ def t3_inference_turbo_batch(model: T3Model, embeds_list: Sequence, text_tokens_
 
 def t3_inference_turbo(model: T3Model, cond, text_tokens=None, max_new_tokens: int = 1000, temperature: float = 0.8,
                        top_k: int = 1000, top_p: float = 0.95, repetition_penalty: float = 1.2,
-                       seed: int = 0) -> np.ndarray:
+                       seed: Optional[int] = None) -> np.ndarray:
     """R/t3.R:1578-1677: no CFG, no position term on the generated tokens, top-k / top-p logit processors; a
     trailing stop token is removed (:1667-1671).  `cond` is a T3Cond with `text_tokens` (the reference's
     signature) or a [1, S0, d] prompt array."""
@@ -360,7 +367,9 @@ def split_sentences(text: str) -> List[str]:
     import re
     if text == "":
         return []
-    parts = re.split(r"(?<=[.!?])\s+", text)
+    # re.ASCII: R's strsplit(perl = TRUE) runs PCRE without UCP, where \s is the ASCII white space only -- a no-break space
+    # (U+00A0) or an em space after a full stop does NOT split there
+    parts = re.split(r"(?<=[.!?])\s+", text, flags=re.ASCII)
     if parts and parts[-1] == "":
         parts = parts[:-1]
     return parts
@@ -372,8 +381,11 @@ def tts_chunked(model: T3Model, text: str, cond: T3Cond, tokenize, chunk_size: i
     reference does, every sentence is tokenised by `tokenize(sentence) -> text token ids` (the reference's BPE
     tokenizer, or punc_norm + the GPT-2 tokenizer on Turbo: R/tts.R:278-285 -- host string work, out of scope
     here), and the sentences go through T3 either as ONE batch (`batched`, the default: the sentences are
-    independent) or one after the other like the reference's loop (R/tts.R:466-474).  Both give
-    the same tokens: every sentence keeps its own RNG stream (seed, sentence index).  `chunk_size` is accepted
+    independent) or one after the other like the reference's loop (R/tts.R:466-474).  In both orders
+    every sentence draws from its own RNG stream (seed, sentence index); the tokens are the same whenever both orders
+    run the same kernel regime (greedy fp32: identical to the oracle in both, test_tts_chunked_batch_equals_serial),
+    otherwise a draw within rounding of a CDF step may differ (8 rows run MFMA GEMMs, 2 rows GEMVs: other summation
+    order).  `chunk_size` is accepted
     and unused, as in the reference.  Keyword arguments are those of t3_inference / t3_inference_turbo
     (generate() passes cfg_weight, temperature, top_p, and top_k / repetition_penalty on Turbo: R/tts.R:303-360).
     Returns {"sentences": [...], "speech_tokens": [array per sentence]} with drop_invalid_tokens applied
@@ -381,6 +393,7 @@ def tts_chunked(model: T3Model, text: str, cond: T3Cond, tokenize, chunk_size: i
     sentences = split_sentences(text)
     if not sentences:
         return {"sentences": [], "speech_tokens": []}
+    kw["seed"] = _seed(kw.get("seed"))      # ONE seed per call: sentence i draws from the stream (seed, i) in both orders
     turbo = model.variant == _lib.VARIANT_TURBO
     toks = [np.asarray(tokenize(s), dtype=np.int32).reshape(-1) for s in sentences]
     fn = t3_inference_turbo_batch if turbo else t3_inference_batch

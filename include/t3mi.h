@@ -166,10 +166,12 @@ int t3mi_prompt_shape(t3mi_model* m, const t3mi_cond* cond, int n_text, float cf
  * host array out[rows, s0, d_model] (parity hook; the generate calls below keep the prompt in HBM). */
 int t3mi_prepare_input_embeds(t3mi_model* m, const t3mi_cond* cond, const int32_t* text_tokens, int n_text,
                               float cfg_weight, int32_t start_token, float* out, size_t cap_floats);
-/* t3mi_prepare_input_embeds for callers that cannot allocate (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  NO counterpart in the reference.  Same inputs and same values as
+/* t3mi_prepare_input_embeds for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, code
+ * that holds a HIP graph capture open on ANOTHER stream in thread-local or relaxed mode: the call enqueues on the model's
+ * own stream and waits for it, so it can neither be captured into the caller's graph nor run while a global-mode capture
+ * is open).  NO counterpart in the reference.  Same inputs and same values as
  * t3mi_prepare_input_embeds, but (i) the result [rows, s0, d_model] is written to the CALLER'S DEVICE buffer
- * `out_device` (on the model's GPU) and (ii) all working memory (uploaded ids, speaker vector, the perceiver's
+ * `out_device` (device memory on the model's GPU; checked with hipPointerGetAttributes, a host pointer is T3MI_ERR_ARG) and (ii) all working memory (uploaded ids, speaker vector, the perceiver's
  * intermediate rows) lives in a fixed 8.02 MiB array inside the library's code object, one copy per GPU, held until the
  * process ends: the call makes no hipMalloc / hipFree.  Limits (T3MI_ERR_ARG beyond them, with the numbers in the
  * message): n_cond + n_text + 3 <= 4096 ids, speaker embedding <= 1024 floats, (4 * max(n_cond, n_query) + 4 * n_query)

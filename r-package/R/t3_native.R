@@ -44,6 +44,11 @@ t3mi_model <- function (path = NULL, device = 0L, dtype = c("f32", "bf16"), vari
     .t3mi[[key]]
 }
 
+# Seed of the library's counter RNG.  The reference draws from torch's global generator (torch_multinomial, R/t3.R:566), so
+# repeated calls differ and torch_manual_seed() governs; the native sampler has its own stream (libtorch's cannot be
+# reproduced), so a call without an explicit `seed` takes one from R's RNG: set.seed() governs, repeated calls differ.
+.t3mi_seed <- function (seed) if (is.null(seed)) as.double(sample.int(.Machine$integer.max, 1L)) else as.double(seed)
+
 # t3_cond (R/t3.R:103-113) as the plain vectors the native prompt builder takes
 .t3mi_cond <- function (cond)
 {
@@ -90,11 +95,11 @@ t3mi_model <- function (path = NULL, device = 0L, dtype = c("f32", "bf16"), vari
 t3_inference <- function (model, cond, text_tokens, max_new_tokens = 1000,
                           temperature = 0.8, cfg_weight = 0.5, top_p = 0.95,
                           min_p = 0.05, repetition_penalty = 1.2,
-                          native = t3mi_model())
+                          native = t3mi_model(), seed = NULL)
 {
     cfg <- list(max_tokens = as.integer(max_new_tokens), temperature = as.double(temperature),
                 cfg_weight = as.double(cfg_weight), top_p = as.double(top_p), min_p = as.double(min_p),
-                rep_penalty = as.double(repetition_penalty))
+                rep_penalty = as.double(repetition_penalty), seed = .t3mi_seed(seed))
     r <- .t3mi_decode(model, cond, text_tokens, cfg, native, sampler = 0L)
     if (length(r$ids) && r$ids[length(r$ids)] == r$stop) message("EOS detected at step ", length(r$ids))
     if (length(r$ids) > 0) torch::torch_tensor(r$ids, dtype = torch::torch_long(), device = r$device)
@@ -105,11 +110,11 @@ t3_inference <- function (model, cond, text_tokens, max_new_tokens = 1000,
 t3_inference_cpp <- function (model, cond, text_tokens, max_new_tokens = 1000,
                               temperature = 0.8, cfg_weight = 0.5, top_p = 0.95,
                               min_p = 0.05, repetition_penalty = 1.2, max_cache_len = 350L,
-                              native = t3mi_model())
+                              native = t3mi_model(), seed = NULL)
 {
     cfg <- list(max_tokens = as.integer(max_new_tokens), temperature = as.double(temperature),
                 cfg_weight = as.double(cfg_weight), top_p = as.double(top_p), min_p = as.double(min_p),
-                rep_penalty = as.double(repetition_penalty))
+                rep_penalty = as.double(repetition_penalty), seed = .t3mi_seed(seed))
     r <- .t3mi_decode(model, cond, text_tokens, cfg, native, sampler = 1L, max_cache_len = max_cache_len)
     ids <- r$ids
     eos <- match(r$stop, ids)
@@ -127,11 +132,11 @@ t3_inference_cpp <- function (model, cond, text_tokens, max_new_tokens = 1000,
 t3_inference_traced <- function (model, cond, text_tokens, max_new_tokens = 1000,
                                  temperature = 0.8, cfg_weight = 0.5, top_p = 0.95,
                                  min_p = 0.05, repetition_penalty = 1.2, max_cache_len = 350L,
-                                 native = t3mi_model())
+                                 native = t3mi_model(), seed = NULL)
 {
     cfg <- list(max_tokens = as.integer(max_new_tokens), temperature = as.double(temperature),
                 cfg_weight = as.double(cfg_weight), top_p = as.double(top_p), min_p = as.double(min_p),
-                rep_penalty = as.double(repetition_penalty))
+                rep_penalty = as.double(repetition_penalty), seed = .t3mi_seed(seed))
     r <- suppressWarnings(.t3mi_decode(model, cond, text_tokens, cfg, native, sampler = 0L,
                                        max_cache_len = max_cache_len))
     if (length(r$ids) && r$ids[length(r$ids)] == r$stop) message("EOS detected at step ", length(r$ids))
@@ -144,13 +149,13 @@ t3_inference_traced <- function (model, cond, text_tokens, max_new_tokens = 1000
 t3_inference_turbo <- function (model, cond, text_tokens, max_new_tokens = 1000,
                                 temperature = 0.8, top_k = 1000L, top_p = 0.95,
                                 repetition_penalty = 1.2,
-                                native = t3mi_model(variant = "turbo"))
+                                native = t3mi_model(variant = "turbo"), seed = NULL)
 {
     config <- model$config
     device <- model$speech_emb$weight$device
     cfg <- list(max_tokens = as.integer(max_new_tokens), temperature = as.double(temperature),
                 cfg_weight = 0, top_k = as.integer(top_k), top_p = as.double(top_p), min_p = 0,
-                rep_penalty = as.double(repetition_penalty), sampler = 2L,
+                rep_penalty = as.double(repetition_penalty), sampler = 2L, seed = .t3mi_seed(seed),
                 start_token = as.integer(config$start_speech_token),
                 stop_token = as.integer(config$stop_speech_token))
     # prompt (speaker row + prompt-token embeddings + text embeddings + BOS, R/t3.R:1447-1477) built on the GPU
@@ -170,13 +175,13 @@ t3_inference_turbo <- function (model, cond, text_tokens, max_new_tokens = 1000,
 t3_inference_batch <- function (model, conds, text_tokens_list, max_new_tokens = 1000,
                                 temperature = 0.8, cfg_weight = 0.5, top_p = 0.95,
                                 min_p = 0.05, repetition_penalty = 1.2,
-                                native = t3mi_model())
+                                native = t3mi_model(), seed = NULL)
 {
     config <- model$config
     device <- model$text_emb$weight$device
     cfg <- list(max_tokens = as.integer(max_new_tokens), temperature = as.double(temperature),
                 cfg_weight = as.double(cfg_weight), top_p = as.double(top_p), min_p = as.double(min_p),
-                rep_penalty = as.double(repetition_penalty), sampler = 0L,
+                rep_penalty = as.double(repetition_penalty), sampler = 0L, seed = .t3mi_seed(seed),
                 start_token = as.integer(config$start_speech_token),
                 stop_token = as.integer(config$stop_speech_token))
     ids <- .Call("t3mi_r_generate_tokens", native, lapply(conds, .t3mi_cond),
@@ -187,13 +192,13 @@ t3_inference_batch <- function (model, conds, text_tokens_list, max_new_tokens =
 #' Turbo counterpart of t3_inference_batch: per-sentence semantics of t3_inference_turbo (trailing stop token removed).
 t3_inference_turbo_batch <- function (model, conds, text_tokens_list, max_new_tokens = 1000,
                                       temperature = 0.8, top_k = 1000L, top_p = 0.95, repetition_penalty = 1.2,
-                                      native = t3mi_model(variant = "turbo"))
+                                      native = t3mi_model(variant = "turbo"), seed = NULL)
 {
     config <- model$config
     device <- model$speech_emb$weight$device
     cfg <- list(max_tokens = as.integer(max_new_tokens), temperature = as.double(temperature),
                 cfg_weight = 0, top_k = as.integer(top_k), top_p = as.double(top_p), min_p = 0,
-                rep_penalty = as.double(repetition_penalty), sampler = 2L,
+                rep_penalty = as.double(repetition_penalty), sampler = 2L, seed = .t3mi_seed(seed),
                 start_token = as.integer(config$start_speech_token),
                 stop_token = as.integer(config$stop_speech_token))
     ids <- .Call("t3mi_r_generate_tokens", native, lapply(conds, .t3mi_cond),
@@ -205,13 +210,28 @@ t3_inference_turbo_batch <- function (model, conds, text_tokens_list, max_new_to
     })
 }
 
+#' Warn when the native handle reads another file than the one the R model was loaded from (a fine-tuned checkpoint given
+#' to load_chatterbox() by path while t3mi_model() resolved the hub-cache file): the tokens would come from other weights.
+.t3mi_check_source <- function (model, native_path)
+{
+    src <- model$t3_path
+    if (!is.null(src) && !is.null(native_path) && file.exists(src) && normalizePath(src) != normalizePath(native_path))
+        warning("native T3 weights come from '", native_path, "' but the R model was loaded from '", src,
+                "'; pass native = t3mi_model('", src, "')", call. = FALSE)
+    invisible(NULL)
+}
+
 #' tts_chunked (R/tts.R:455-480) with the sentence loop turned into ONE batched T3 call: same arguments, same
 #' sentence split (strsplit(text, "(?<=[.!?])\\s+", perl = TRUE), R/tts.R:462), same per-sentence tokenisation,
 #' conditioning and defaults as generate() (R/tts.R:278-293, 341-348), audio concatenated in sentence order.
-#' Everything after the speech tokens (drop_invalid_tokens, S3Gen, vocoder: R/tts.R:366-412) is the reference's.
+#' Everything after the speech tokens (drop_invalid_tokens, S3Gen under autocast on CUDA, vocoder: R/tts.R:366-412) is the
+#' reference's, including its warning for a sentence that yields no valid token (R/tts.R:368-371).  `devices`: more than
+#' one GPU index spreads the sentences over that many worker processes (t3_inference_sharded below).
 tts_chunked <- function (model, text, voice, chunk_size = 200, exaggeration = 0.5, cfg_weight = 0.5,
                          temperature = 0.8, top_p = 0.9, autocast = NULL, traced = FALSE, top_k = 1000L,
-                         repetition_penalty = 1.2, ...)
+                         repetition_penalty = 1.2, seed = NULL, devices = 0L,
+                         native = t3mi_model(variant = if (isTRUE(model$turbo)) "turbo" else "llama",
+                                             device = devices[1L]))
 {
     if (!is_loaded(model)) stop("Model not loaded. Call load_chatterbox() first.")
     sentences <- strsplit(text, "(?<=[.!?])\\s+", perl = TRUE)[[1]]
@@ -228,23 +248,104 @@ tts_chunked <- function (model, text, voice, chunk_size = 200, exaggeration = 0.
     cond <- t3_cond(speaker_emb = voice$ve_embedding, cond_prompt_speech_tokens = voice$cond_prompt_speech_tokens,
                     emotion_adv = if (is_turbo) NULL else exaggeration)
     conds <- rep(list(cond), length(sentences))
+    seed <- .t3mi_seed(seed)      # ONE seed for the call: sentence i draws from the stream (seed, i) on whichever GPU decodes it
     message(sprintf("Generating speech tokens for %d sentences in one batch...", length(sentences)))
-    speech <- if (is_turbo)
+    speech <- if (length(devices) > 1L)
+        t3_inference_sharded(model$t3, conds, toks, devices = devices, turbo = is_turbo, seed = seed,
+                             cfg_weight = cfg_weight, temperature = temperature, top_p = top_p, top_k = top_k,
+                             repetition_penalty = repetition_penalty)
+    else if (is_turbo)
         t3_inference_turbo_batch(model$t3, conds, toks, temperature = temperature, top_k = top_k, top_p = top_p,
-                                 repetition_penalty = repetition_penalty)
+                                 repetition_penalty = repetition_penalty, native = native, seed = seed)
     else
-        t3_inference_batch(model$t3, conds, toks, cfg_weight = cfg_weight, temperature = temperature, top_p = top_p)
+        t3_inference_batch(model$t3, conds, toks, cfg_weight = cfg_weight, temperature = temperature, top_p = top_p,
+                           native = native, seed = seed)
     all_audio <- numeric(0)
     for (i in seq_along(sentences)) {
         tk <- drop_invalid_tokens(speech[[i]])
-        if (length(tk) == 0L) next
+        if (length(tk) == 0L) {
+            warning("No valid speech tokens generated")              # R/tts.R:368-371
+            next
+        }
         vals <- as.integer(tk)
         if (is_turbo) vals <- c(vals, rep(S3GEN_SIL, 3L))
         st <- torch::torch_tensor(vals, dtype = torch::torch_long())$unsqueeze(1L)$to(device = device)
-        audio <- torch::with_no_grad(model$s3gen$inference(speech_tokens = st, ref_dict = voice$ref_dict, finalize = TRUE,
-                                                           traced = traced,
-                                                           n_cfm_timesteps = if (is_turbo) 2L else NULL)[[1]])
+        synth <- function ()
+            model$s3gen$inference(speech_tokens = st, ref_dict = voice$ref_dict, finalize = TRUE, traced = traced,
+                                  n_cfm_timesteps = if (is_turbo) 2L else NULL)[[1]]
+        audio <- torch::with_no_grad({
+            if (use_autocast) torch::with_autocast(device_type = "cuda", synth())    # R/tts.R:389-401
+            else synth()
+        })
         all_audio <- c(all_audio, as.numeric(audio$squeeze()$cpu()))
     }
     list(audio = all_audio, sample_rate = S3GEN_SR)
+}
+
+#' The utterance sharder of SURVEY §8e on the R side: the loop tts_chunked runs serially (R/tts.R:466-474) spread over the
+#' GPUs of one node.  One worker PROCESS per device (parallel::makeCluster; each opens its own t3mi_model(device = i) --
+#' weights replicated, 2 GB fp32 / 1 GB bf16 of 288 GB), utterance u goes to worker floor(u * G / U) (contiguous blocks, the
+#' partition of chatterbox_amd/shard.py), every worker decodes its block as ONE batched call with first_utterance_id = the
+#' block's first global index, so a sampled utterance draws from the stream (seed, u) whatever the number of GPUs; the only
+#' exchange is the integer token vectors coming back, in utterance order.  No collective, nothing crosses xGMI.  Workers and
+#' their handles are cached for the session (weights stay resident); `t3mi_cluster_stop()` ends them.
+t3_inference_sharded <- function (model, conds, text_tokens_list, devices = 0L, turbo = FALSE, seed = NULL,
+                                  max_new_tokens = 1000, temperature = 0.8, cfg_weight = 0.5, top_p = 0.95, min_p = 0.05,
+                                  top_k = 1000L, repetition_penalty = 1.2, dtype = "f32", path = NULL)
+{
+    U <- length(conds)
+    G <- length(devices)
+    stopifnot(U > 0L, G > 0L, length(text_tokens_list) == U)
+    config <- model$config
+    out_device <- model$speech_emb$weight$device
+    variant <- if (turbo) "turbo" else "llama"
+    if (is.null(path)) path <- t3mi_default_path(variant)
+    cfg <- list(max_tokens = as.integer(max_new_tokens), temperature = as.double(temperature),
+                cfg_weight = if (turbo) 0 else as.double(cfg_weight), top_p = as.double(top_p),
+                min_p = if (turbo) 0 else as.double(min_p), top_k = as.integer(top_k),
+                rep_penalty = as.double(repetition_penalty), sampler = if (turbo) 2L else 0L,
+                start_token = as.integer(config$start_speech_token), stop_token = as.integer(config$stop_speech_token),
+                seed = .t3mi_seed(seed))
+    plain_conds <- lapply(conds, .t3mi_cond)                       # plain vectors: they travel to the workers
+    plain_text <- lapply(text_tokens_list, function (t) as.integer(t$cpu()))
+    owner <- (seq_len(U) - 1L) * G %/% U                            # utterance u (0-based) -> worker floor(u * G / U)
+    cl <- .t3mi_cluster(devices)
+    jobs <- lapply(seq_len(G), function (g) {
+        mine <- which(owner == g - 1L)
+        list(device = as.integer(devices[g]), idx = mine, conds = plain_conds[mine], text = plain_text[mine],
+             cfg = c(cfg, list(first_utterance_id = as.double(if (length(mine)) mine[1L] - 1L else 0))),
+             path = path, variant = variant, dtype = dtype)
+    })
+    parts <- parallel::clusterApply(cl, jobs, function (job) {
+        if (!length(job$idx)) return(list())
+        h <- chatterbox:::t3mi_model(job$path, device = job$device, dtype = job$dtype, variant = job$variant)
+        .Call("t3mi_r_generate_tokens", h, job$conds, job$text, job$cfg, PACKAGE = "chatterbox")
+    })
+    ids <- vector("list", U)
+    for (g in seq_len(G)) ids[jobs[[g]]$idx] <- parts[[g]]
+    lapply(ids, function (v) {
+        n <- length(v)
+        if (turbo && n > 0L && v[n] == config$stop_speech_token) v <- v[seq_len(n - 1L)]      # R/t3.R:1667-1671
+        torch::torch_tensor(v, dtype = torch::torch_long(), device = out_device)
+    })
+}
+
+.t3mi_cluster <- function (devices)
+{
+    key <- paste("cluster", paste(devices, collapse = ","))
+    if (is.null(.t3mi[[key]])) {
+        cl <- parallel::makeCluster(length(devices))               # PSOCK workers: fresh processes, no GPU state inherited
+        parallel::clusterEvalQ(cl, library(chatterbox))
+        .t3mi[[key]] <- cl
+    }
+    .t3mi[[key]]
+}
+
+t3mi_cluster_stop <- function ()
+{
+    for (k in grep("^cluster ", ls(.t3mi), value = TRUE)) {
+        parallel::stopCluster(.t3mi[[k]])
+        rm(list = k, envir = .t3mi)
+    }
+    invisible(NULL)
 }

@@ -7,8 +7,9 @@
  * a plain numeric [rows, S0, d] array, and the decode parameters are the SAME named list the reference builds at
  * R/t3.R:1022-1034 (read by name, like src/t3_decode.cpp:43-64, 221-231).
  *
- * Not compiled in the build container (no R headers there); compiled by the package's
- * `configure` + R CMD INSTALL on a machine with R and ROCm.  Plain C, R API only.
+ * Compiled by the package's `configure` + R CMD INSTALL on a machine with R and ROCm; in the build container (no R) it is
+ * compiled against a test double of the R C API and driven like .Call (tests/r_mock/, tests/test_gpu_r_glue.py).
+ * Plain C, R API only.
  */
 #include <R.h>
 #include <Rinternals.h>

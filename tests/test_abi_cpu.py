@@ -61,3 +61,23 @@ def test_synthetic_checkpoint_layout_roundtrip(tmp_path):
     for k in w:
         assert np.array_equal(back[k], w[k])
     assert "tfmr.layers.1.mlp.down_proj.weight" in w and "speech_pos_emb.emb.weight" in w
+
+
+def test_sentence_split_uses_ascii_whitespace_like_R():
+    """R/tts.R:462: strsplit(text, "(?<=[.!?])\\s+", perl = TRUE) -- PCRE without UCP: a no-break space or an em space after
+    the full stop is not white space there."""
+    from chatterbox_amd import split_sentences
+    assert split_sentences("One.\u00a0Two. Three!\u2003Four?\tFive") == ["One.\u00a0Two.", "Three!\u2003Four?", "Five"]
+    assert split_sentences("A. B.  ") == ["A.", "B."]
+    assert split_sentences("") == []
+
+
+def test_seed_default_follows_the_global_generator():
+    """Without `seed` the wrappers draw one from numpy's global generator (the reference draws from torch's, R/t3.R:566):
+    np.random.seed governs, consecutive calls differ; an explicit seed is passed through."""
+    import numpy as np
+    from chatterbox_amd import t3
+    np.random.seed(5)
+    a, b = t3._seed(None), t3._seed(None)
+    np.random.seed(5)
+    assert t3._seed(None) == a and a != b and t3._seed(17) == 17

@@ -103,3 +103,48 @@ def test_strong_scaling_path_single_process():
     cb = types.SimpleNamespace(Session=_FakeSession)
     r = bench.sharded_workload(rk, cb, types.SimpleNamespace(info=_fake_info()), 5, 8, "bf16", 4, 0, 64)
     assert r["ranks"] == 1 and r["token_checksum"] == _expected_checksum(5, 4, 0)
+
+
+def _force_dist_worker(q):
+    for k in ("MASTER_PORT", "RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    rk = bench.Ranks(1, 0, 0, "gloo", force_dist=True)
+    try:
+        assert rk.dist is not None and rk.dist.get_world_size() == 1
+        assert rk.max(3.0, 1.5) == [3.0, 1.5]                     # a real all-reduce in a one-rank group
+        cb = types.SimpleNamespace(Session=_FakeSession)
+        r = bench.sharded_workload(rk, cb, types.SimpleNamespace(info=_fake_info()), 5, 8, "bf16", 4, 0, 64)
+        q.put(r)
+    finally:
+        rk.close()
+
+
+def test_force_dist_runs_the_group_path_with_one_rank():
+    """--force-dist: init_process_group, barrier, MAX all-reduce and all_gather_object all execute in a
+    one-rank group (gloo here; `nccl` on the GPU box, profiles/r03_bench_nccl_world1.json)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_force_dist_worker, args=(q,))
+    p.start()
+    r = q.get(timeout=180)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert r["ranks"] == 1 and r["token_checksum"] == _expected_checksum(5, 4, 0)
+
+
+def test_spawn_parent_fails_when_a_rank_dies(tmp_path, monkeypatch):
+    """Without a launcher the parent starts the ranks: one rank exiting non-zero must end the run non-zero promptly (the
+    others would wait at a barrier), and no JSON line is printed."""
+    fake = tmp_path / "fake_rank.py"
+    fake.write_text("import os, sys, time\n"
+                    "if os.environ['RANK'] == '1':\n    sys.exit(7)\n"
+                    "time.sleep(120)\nprint('{\"never\": 1}')\n")
+    monkeypatch.setattr(bench, "__file__", str(fake))
+    import io
+    import contextlib
+    import time as _t
+    out = io.StringIO()
+    t0 = _t.time()
+    with contextlib.redirect_stdout(out):
+        rc = bench.spawn_ranks(3, [])
+    assert rc == 7 and out.getvalue() == "" and _t.time() - t0 < 60

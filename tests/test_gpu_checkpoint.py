@@ -118,6 +118,16 @@ def test_packed_bf16_cache(tmp_path, variant):
     os.utime(src, (later, later))
     assert run(cache=True)[0] == _lib.CACHE_REPLACED
     assert run(cache=True)[0] == _lib.CACHE_USED
+    # a same-architecture fine-tune copied over the checkpoint with size AND mtime preserved (cp -p): only the content
+    # fingerprint in the header can tell -- the cache is stale, the new weights are the ones that run
+    st_src = os.stat(src)
+    w2 = synth.synth_llama_weights(dims, 4242) if variant == "llama" else synth.synth_turbo_weights(dims, 4242)
+    synth.write_safetensors(w2, src)
+    os.utime(src, ns=(st_src.st_atime_ns, st_src.st_mtime_ns))
+    assert os.stat(src).st_size == st_src.st_size and os.stat(src).st_mtime_ns == st_src.st_mtime_ns
+    st6, f, _ = run(cache=True)
+    assert st6 == _lib.CACHE_REPLACED and not np.array_equal(f[1], base[1])
+    assert run(cache=True)[0] == _lib.CACHE_USED
     # a cache of ANOTHER checkpoint under this name is refused
     other = synth.write_safetensors(synth.synth_llama_weights(synth.TINY, 99) if variant == "llama" else
                                     synth.synth_turbo_weights(synth.TURBO_TINY, 99), str(tmp_path / "other.safetensors"))

@@ -22,10 +22,14 @@ def _static(model, cond, text, cfg_weight):
     _lib.check(model._lib.t3mi_prompt_shape(model._h, C.byref(cs), tt.size, float(cfg_weight), C.byref(rows), C.byref(s0),
                                             C.byref(lc)))
     out = torch.full((rows.value, s0.value, model.d_model), float("nan"), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)             # hipMemGetInfo: the device's free bytes, whoever allocated
     rc = model._lib.t3mi_prepare_input_embeds_static(model._h, C.byref(cs), tt.ctypes.data_as(C.POINTER(C.c_int32)), tt.size,
                                                      float(cfg_weight), model.start_speech_token, C.c_void_p(out.data_ptr()),
                                                      out.numel())
+    free1, _ = torch.cuda.mem_get_info(0)
     _lib.check(rc)
+    assert free1 == free0, f"the static entry point changed the device's free memory by {free0 - free1} bytes"
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -51,6 +55,14 @@ def test_static_entry_point_matches_the_allocating_one(dims):
             with pytest.raises(_lib.T3miError) as e:
                 _static(model, cond, rng.integers(1, 250, 200), 0.5)
             assert e.value.code == _lib.ERR_ARG and "exceed the fixed working memory" in str(e.value)
+            # a HOST pointer in the device-buffer slot (the sibling entry point takes one there) is refused, not dereferenced
+            host = np.zeros((2, 64, dims.hidden_size), dtype=np.float32)
+            small = cb.t3_cond(spk, rng.integers(0, dims.start_speech_token, 10), emotion_adv=0.3)
+            cs = small.c_struct()
+            t5 = np.arange(1, 6, dtype=np.int32)
+            rc = model._lib.t3mi_prepare_input_embeds_static(model._h, C.byref(cs), t5.ctypes.data_as(C.POINTER(C.c_int32)), 5, 0.5,
+                                                             model.start_speech_token, C.c_void_p(host.ctypes.data), host.size)
+            assert rc == _lib.ERR_ARG and b"device memory" in model._lib.t3mi_last_error()
             # ... and the allocating entry point still takes it
             want, _ = cb.prepare_input_embeds(model, cond, rng.integers(1, 250, 200), cfg_weight=0.5)
             assert np.isfinite(want).all()
