@@ -236,3 +236,107 @@ def ensure_checkpoint(dims: T3Dims, seed: int = 1234, root: str | None = None, h
     if not os.path.exists(path):
         write_safetensors(synth_llama_weights(dims, seed, head_scale), path)
     return path
+
+
+# ---- S3Gen flow decoder: the CFM estimator ------------------------------------------------------------
+
+@dataclass(frozen=True)
+class CfmDims:
+    """Shapes of cfm_estimator (R/s3gen.R:389-444): in = x + mu + spks + cond = 4 x mel bins."""
+    mel: int = 80
+    hidden: int = 256
+    n_mid: int = 12
+    n_tfm: int = 4
+    heads: int = 8
+    head_dim: int = 64
+    time_in: int = 320          # sinusoidal_pos_emb(320), R/s3gen.R:400
+    time_dim: int = 1024        # timestep_embedding(320, 1024), R/s3gen.R:401
+    meanflow: bool = False
+
+
+CFM_FULL = CfmDims()
+CFM_TINY = CfmDims(mel=16, hidden=64, n_mid=2, n_tfm=1, heads=2, head_dim=64, time_in=64, time_dim=128)
+CFM_PREFIX = "flow.decoder.estimator."      # load_s3gen_weights, R/s3gen.R:1231
+
+
+def synth_cfm_weights(dims: CfmDims = CFM_FULL, seed: int = 777, prefix: str = CFM_PREFIX) -> Dict[str, np.ndarray]:
+    """A synthetic checkpoint in the key layout load_cfm_estimator_weights reads (R/s3gen.R:1070-1178): conv weights
+    [out, in, k], linear weights [out, in].  Scales keep every activation O(1) through 56 residual blocks (weights
+    ~ 0.7 / sqrt(fan_in), LayerNorm weights 1 + N(0, .1^2), biases N(0, .05^2))."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    C, inner, Tm = dims.hidden, dims.heads * dims.head_dim, dims.time_dim
+    w: Dict[str, np.ndarray] = {}
+
+    def lin(name, o, i, bias=True, gain=0.7):
+        w[prefix + name + ".weight"] = (rng.standard_normal((o, i), dtype=F32) * F32(gain / np.sqrt(i))).astype(F32)
+        if bias:
+            w[prefix + name + ".bias"] = (rng.standard_normal(o, dtype=F32) * F32(0.05)).astype(F32)
+
+    def conv(name, o, i, k, gain=0.7):
+        w[prefix + name + ".weight"] = (rng.standard_normal((o, i, k), dtype=F32) * F32(gain / np.sqrt(i * k))).astype(F32)
+        w[prefix + name + ".bias"] = (rng.standard_normal(o, dtype=F32) * F32(0.05)).astype(F32)
+
+    def norm(name, n):
+        w[prefix + name + ".weight"] = (F32(1) + rng.standard_normal(n, dtype=F32) * F32(0.1)).astype(F32)
+        w[prefix + name + ".bias"] = (rng.standard_normal(n, dtype=F32) * F32(0.05)).astype(F32)
+
+    def resnet(p, cin):
+        conv(p + "block1.block.0", C, cin, 3)
+        norm(p + "block1.block.2", C)
+        conv(p + "block2.block.0", C, C, 3)
+        norm(p + "block2.block.2", C)
+        lin(p + "mlp.1", C, Tm)
+        conv(p + "res_conv", C, cin, 1)
+
+    def tfm(p):
+        norm(p + "norm1", C)
+        lin(p + "attn1.to_q", inner, C, bias=False, gain=1.0)
+        lin(p + "attn1.to_k", inner, C, bias=False, gain=1.0)
+        lin(p + "attn1.to_v", inner, C, bias=False)
+        lin(p + "attn1.to_out.0", C, inner, gain=0.4)
+        norm(p + "norm3", C)
+        lin(p + "ff.net.0.proj", 4 * C, C)
+        lin(p + "ff.net.2", C, 4 * C, gain=0.4)
+
+    lin("time_mlp.linear_1", Tm, dims.time_in)
+    lin("time_mlp.linear_2", Tm, Tm)
+    if dims.meanflow:
+        lin("time_embed_mixer", Tm, 2 * Tm, bias=False)
+    resnet("down_blocks.0.0.", 4 * dims.mel)
+    for i in range(dims.n_tfm):
+        tfm(f"down_blocks.0.1.{i}.")
+    conv("down_blocks.0.2", C, C, 3)
+    for m in range(dims.n_mid):
+        resnet(f"mid_blocks.{m}.0.", C)
+        for j in range(dims.n_tfm):
+            tfm(f"mid_blocks.{m}.1.{j}.")
+    resnet("up_blocks.0.0.", 2 * C)
+    for i in range(dims.n_tfm):
+        tfm(f"up_blocks.0.1.{i}.")
+    conv("up_blocks.0.2", C, C, 3)
+    conv("final_block.block.0", C, C, 3)
+    norm("final_block.block.2", C)
+    conv("final_proj", dims.mel, C, 1)
+    return w
+
+
+def ensure_cfm_checkpoint(dims: CfmDims = CFM_FULL, seed: int = 777, root: str | None = None) -> str:
+    root = root or os.environ.get("T3MI_SYNTH_DIR", "/tmp/t3mi_synth")
+    os.makedirs(root, exist_ok=True)
+    tag = f"s3gen_cfm_C{dims.hidden}_M{dims.n_mid}x{dims.n_tfm}_mel{dims.mel}_t{dims.time_dim}_s{seed}" + ("_mf" if dims.meanflow else "")
+    path = os.path.join(root, tag + ".safetensors")
+    if not os.path.exists(path):
+        write_safetensors(synth_cfm_weights(dims, seed), path)
+    return path
+
+
+def synth_cfm_inputs(dims: CfmDims, T: int, seed: int, B: int = 1):
+    """mu, spks, cond, z for one solve, in the reference's layouts: (B, mel, T), (B, mel), (B, mel, T), (B, mel, T).
+    cond is a prompt mel over the first third of the frames and zero after it (R/s3gen.R:857-866)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mu = rng.standard_normal((B, dims.mel, T), dtype=F32)
+    spks = (rng.standard_normal((B, dims.mel), dtype=F32) * F32(0.5)).astype(F32)
+    cond = np.zeros((B, dims.mel, T), F32)
+    cond[:, :, : T // 3] = rng.standard_normal((B, dims.mel, T // 3), dtype=F32)
+    z = rng.standard_normal((B, dims.mel, T), dtype=F32)
+    return mu, spks, cond, z

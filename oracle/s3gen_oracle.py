@@ -1,0 +1,238 @@
+"""CPU restatement (numpy, fp32) of chatterbox's S3Gen flow-matching decoder: the CFM estimator and its Euler solvers.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``chatterbox_amd/`` imports this module; only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s CPU-baseline leg may.  It is the checker, never the thing measured or
+shipped.
+
+What it restates (citations into /root/reference, read as text) -- SURVEY §8 row f4, first closed piece:
+
+* sinusoidal_pos_emb / timestep_embedding ........ R/s3gen.R:64-115
+* causal_conv1d / causal_block1d (conv+LN+Mish) .. R/s3gen.R:124-197
+* causal_resnet_block1d ......................... R/s3gen.R:204-231
+* cfm_attention (8 x 64, no mask) ............... R/s3gen.R:238-291
+* gelu_with_proj / feed_forward ................. R/s3gen.R:297-342
+* basic_transformer_block ....................... R/s3gen.R:348-373
+* cfm_estimator$forward ......................... R/s3gen.R:446-520
+* causal_cfm$forward / solve_euler / basic_euler  R/s3gen.R:594-751
+
+PARITY UNPINNED against the reference: it ships no S3Gen fixture (outputs/ holds T3 dumps only) and the
+weights (s3gen.safetensors) are not in the container.  What pins this restatement is an op-for-op run of the same
+sequence on CPU libtorch through python `torch` (tests/test_s3gen_oracle_vs_torch.py): nn.Conv1d, F.layer_norm,
+F.softplus, F.gelu(approximate="tanh"), softmax, matmul -- the ATen kernels R torch dispatches to.
+
+Layouts follow the reference: sequences are (B, C, T); weights are the tensors of `load_cfm_estimator_weights`
+(R/s3gen.R:1070-1178) under their checkpoint keys (conv weights [out, in, k], linear weights [out, in]).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+
+F32 = np.float32
+
+
+def _lin(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:
+    y = x.astype(F32) @ w.astype(F32).T
+    if b is not None:
+        y = y + b.astype(F32)
+    return y.astype(F32)
+
+
+def silu(x):
+    return (x / (F32(1) + np.exp(-x, dtype=F32))).astype(F32)
+
+
+def softplus(x):
+    # torch.nn.functional.softplus: beta 1, threshold 20 (x above it is returned unchanged)
+    x = x.astype(F32)
+    return np.where(x > F32(20), x, np.log1p(np.exp(np.minimum(x, F32(20)), dtype=F32), dtype=F32)).astype(F32)
+
+
+def mish(x):
+    """R/s3gen.R:165-168: x * tanh(softplus(x))."""
+    return (x * np.tanh(softplus(x), dtype=F32)).astype(F32)
+
+
+def gelu_tanh(x):
+    x = x.astype(F32)
+    inner = F32(0.7978845608028654) * (x + F32(0.044715) * x * x * x)
+    return (F32(0.5) * x * (F32(1) + np.tanh(inner, dtype=F32))).astype(F32)
+
+
+def layer_norm(x, w, b, eps=1e-5):
+    """torch::nn_layer_norm over the last axis (biased variance, eps 1e-5)."""
+    x = x.astype(F32)
+    mu = x.mean(axis=-1, keepdims=True, dtype=F32)
+    xc = (x - mu).astype(F32)
+    var = (xc * xc).mean(axis=-1, keepdims=True, dtype=F32)
+    return ((xc / np.sqrt(var + F32(eps), dtype=F32)) * w.astype(F32) + b.astype(F32)).astype(F32)
+
+
+def sinusoidal_pos_emb(t: np.ndarray, dim: int = 320, scale: float = 1000.0) -> np.ndarray:
+    """R/s3gen.R:72-91.  t [B] -> [B, dim] = cat(sin, cos) of (scale * t) * exp(arange(half) * -log(1e4) / (half - 1))."""
+    t = np.asarray(t, dtype=F32).reshape(-1)
+    half = dim // 2
+    emb = np.exp(np.arange(half, dtype=F32) * F32(-math.log(10000.0) / (half - 1)), dtype=F32)
+    e = ((F32(scale) * t)[:, None] * emb[None, :]).astype(F32)
+    return np.concatenate([np.sin(e, dtype=F32), np.cos(e, dtype=F32)], axis=-1).astype(F32)
+
+
+def causal_conv1d(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """R/s3gen.R:138-142: left-pad (k - 1) zeros, conv1d.  x (B, Cin, T), w [Cout, Cin, k] -> (B, Cout, T)."""
+    B, Cin, T = x.shape
+    k = w.shape[2]
+    xp = np.concatenate([np.zeros((B, Cin, k - 1), F32), x.astype(F32)], axis=2)
+    y = np.zeros((B, w.shape[0], T), F32)
+    for j in range(k):
+        # out[:, o, t] += sum_c w[o, c, j] * xp[:, c, t + j]
+        y += np.einsum("oc,bct->bot", w[:, :, j].astype(F32), xp[:, :, j:j + T]).astype(F32)
+    return (y + b.astype(F32)[None, :, None]).astype(F32)
+
+
+class CfmEstimatorOracle:
+    """cfm_estimator (R/s3gen.R:389-528) over a dict of checkpoint tensors with `prefix` stripped."""
+
+    def __init__(self, weights: Dict[str, np.ndarray], prefix: str = "flow.decoder.estimator.", heads: int = 8,
+                 head_dim: int = 64, time_in: int = 320):
+        self.w = {k[len(prefix):]: np.asarray(v, dtype=F32) for k, v in weights.items() if k.startswith(prefix)}
+        self.heads, self.head_dim, self.time_in = heads, head_dim, time_in
+        self.n_mid = 0
+        while f"mid_blocks.{self.n_mid}.0.block1.block.0.weight" in self.w:
+            self.n_mid += 1
+        self.n_tfm = 0
+        while f"down_blocks.0.1.{self.n_tfm}.norm1.weight" in self.w:
+            self.n_tfm += 1
+        self.meanflow = "time_embed_mixer.weight" in self.w
+
+    # -- pieces ---------------------------------------------------------------------------------------------
+    def time_embed(self, t: np.ndarray) -> np.ndarray:
+        w = self.w
+        e = sinusoidal_pos_emb(t, self.time_in)                                      # R/s3gen.R:459
+        e = _lin(e, w["time_mlp.linear_1.weight"], w["time_mlp.linear_1.bias"])
+        e = silu(e)
+        return _lin(e, w["time_mlp.linear_2.weight"], w["time_mlp.linear_2.bias"])   # :460
+
+    def block1d(self, x, mask, p):
+        """causal_block1d (R/s3gen.R:186-196): conv(x * mask) -> LayerNorm over channels -> Mish -> * mask."""
+        w = self.w
+        h = causal_conv1d(x * mask, w[p + "block.0.weight"], w[p + "block.0.bias"])
+        h = layer_norm(h.transpose(0, 2, 1), w[p + "block.2.weight"], w[p + "block.2.bias"]).transpose(0, 2, 1)
+        return (mish(h) * mask).astype(F32)
+
+    def resnet(self, x, mask, temb, p):
+        """causal_resnet_block1d (R/s3gen.R:223-230)."""
+        w = self.w
+        h = self.block1d(x, mask, p + "block1.")
+        h = (h + _lin(mish(temb), w[p + "mlp.1.weight"], w[p + "mlp.1.bias"])[:, :, None]).astype(F32)
+        h = self.block1d(h, mask, p + "block2.")
+        res = causal_conv1d(x * mask, w[p + "res_conv.weight"], w[p + "res_conv.bias"])   # 1 x 1 conv
+        return (h + res).astype(F32)
+
+    def attention(self, x, p):
+        """cfm_attention (R/s3gen.R:260-290): x (B, T, C); no mask (compute_attn_mask returns NULL, :522-527)."""
+        w = self.w
+        B, T, _ = x.shape
+        H, Dh = self.heads, self.head_dim
+        q = _lin(x, w[p + "to_q.weight"]).reshape(B, T, H, Dh).transpose(0, 2, 1, 3)
+        k = _lin(x, w[p + "to_k.weight"]).reshape(B, T, H, Dh).transpose(0, 2, 1, 3)
+        v = _lin(x, w[p + "to_v.weight"]).reshape(B, T, H, Dh).transpose(0, 2, 1, 3)
+        s = (np.matmul(q, k.transpose(0, 1, 3, 2)).astype(F32) * F32(Dh ** -0.5)).astype(F32)
+        s = s - s.max(axis=-1, keepdims=True)
+        e = np.exp(s, dtype=F32)
+        a = (e / e.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
+        o = np.matmul(a, v).astype(F32).transpose(0, 2, 1, 3).reshape(B, T, H * Dh)
+        return _lin(o, w[p + "to_out.0.weight"], w[p + "to_out.0.bias"])
+
+    def transformer(self, x, p):
+        """basic_transformer_block (R/s3gen.R:359-372)."""
+        w = self.w
+        n = layer_norm(x, w[p + "norm1.weight"], w[p + "norm1.bias"])
+        x = (x + self.attention(n, p + "attn1.")).astype(F32)
+        n = layer_norm(x, w[p + "norm3.weight"], w[p + "norm3.bias"])
+        f = gelu_tanh(_lin(n, w[p + "ff.net.0.proj.weight"], w[p + "ff.net.0.proj.bias"]))
+        f = _lin(f, w[p + "ff.net.2.weight"], w[p + "ff.net.2.bias"])
+        return (x + f).astype(F32)
+
+    # -- forward (R/s3gen.R:446-520) ------------------------------------------------------------------------
+    def forward(self, x, mask, mu, t, spks=None, cond=None, r=None) -> np.ndarray:
+        """x, mu, cond (B, 80, T); mask (B, 1, T); t [B]; spks (B, 80); r [B] (meanflow).  Returns (B, 80, T)."""
+        w = self.w
+        x, mask, mu = x.astype(F32), mask.astype(F32), mu.astype(F32)
+        T = x.shape[2]
+        temb = self.time_embed(t)
+        if self.meanflow and r is not None:                                          # :463-468
+            remb = self.time_embed(r)
+            temb = _lin(np.concatenate([temb, remb], axis=1), w["time_embed_mixer.weight"])
+        h = np.concatenate([x, mu], axis=1)                                          # :471-478
+        if spks is not None:
+            h = np.concatenate([h, np.broadcast_to(spks.astype(F32)[:, :, None], spks.shape + (T,))], axis=1)
+        if cond is not None:
+            h = np.concatenate([h, cond.astype(F32)], axis=1)
+        h = self.resnet(h, mask, temb, "down_blocks.0.0.")                           # :481
+        h = h.transpose(0, 2, 1)
+        for i in range(self.n_tfm):
+            h = self.transformer(h, f"down_blocks.0.1.{i}.")
+        h = h.transpose(0, 2, 1)
+        skip = h                                                                     # :488
+        h = causal_conv1d(h * mask, w["down_blocks.0.2.weight"], w["down_blocks.0.2.bias"])
+        for m in range(self.n_mid):                                                  # :492-499
+            h = self.resnet(h, mask, temb, f"mid_blocks.{m}.0.")
+            h = h.transpose(0, 2, 1)
+            for j in range(self.n_tfm):
+                h = self.transformer(h, f"mid_blocks.{m}.1.{j}.")
+            h = h.transpose(0, 2, 1)
+        h = np.concatenate([h, skip], axis=1)                                        # :503
+        h = self.resnet(h, mask, temb, "up_blocks.0.0.")
+        h = h.transpose(0, 2, 1)
+        for i in range(self.n_tfm):
+            h = self.transformer(h, f"up_blocks.0.1.{i}.")
+        h = h.transpose(0, 2, 1)
+        h = causal_conv1d(h * mask, w["up_blocks.0.2.weight"], w["up_blocks.0.2.bias"])   # :513
+        h = self.block1d(h, mask, "final_block.")                                    # :516
+        return causal_conv1d(h * mask, w["final_proj.weight"], w["final_proj.bias"])      # :517 (1 x 1)
+
+
+def t_span_cosine(n_timesteps: int) -> np.ndarray:
+    """R/s3gen.R:622-625: linspace(0, 1, n + 1) in float32, then 1 - cos(t * 0.5 * pi)."""
+    ts = np.linspace(0.0, 1.0, n_timesteps + 1).astype(F32)
+    return (F32(1) - np.cos((ts * F32(0.5)).astype(F32) * F32(math.pi), dtype=F32)).astype(F32)
+
+
+def solve_euler(est: CfmEstimatorOracle, z, mu, mask, spks, cond, n_timesteps: int = 10, cfg_rate: float = 0.7,
+                keep: Optional[list] = None) -> np.ndarray:
+    """causal_cfm$forward + solve_euler, untraced (R/s3gen.R:594-636, 651-751): cosine schedule, classifier-free
+    guidance as a batch of two (row 2: mu, spks, cond zeroed), t accumulated in float32.  z is the start noise
+    (rand_noise[:, :, 1:T] * temperature, :616-619 -- a torch_randn buffer the caller owns).  All (1, 80, T)."""
+    ts = t_span_cosine(n_timesteps)
+    x = z.astype(F32)
+    t = F32(ts[0])
+    dt = F32(ts[1] - ts[0])
+    for step in range(1, len(ts)):                                   # R: step in 2:length(t_span)
+        x_in = np.concatenate([x, x], axis=0)
+        mask_in = np.concatenate([mask, mask], axis=0).astype(F32)
+        mu_in = np.concatenate([mu, np.zeros_like(mu)], axis=0).astype(F32)
+        t_in = np.array([t, t], dtype=F32)
+        spks_in = np.concatenate([spks, np.zeros_like(spks)], axis=0).astype(F32)
+        cond_in = np.concatenate([cond, np.zeros_like(cond)], axis=0).astype(F32)
+        d = est.forward(x_in, mask_in, mu_in, t_in, spks_in, cond_in)
+        if keep is not None:
+            keep.append(d.copy())
+        dphi = (F32(1.0 + cfg_rate) * d[0:1] - F32(cfg_rate) * d[1:2]).astype(F32)      # :734
+        x = (x + dt * dphi).astype(F32)                              # :737
+        t = F32(t + dt)
+        if step < len(ts) - 1:
+            dt = F32(ts[step + 1] - ts[step])                        # :745-747
+    return x
+
+
+def basic_euler(est: CfmEstimatorOracle, z, mu, mask, spks, cond, n_timesteps: int = 2) -> np.ndarray:
+    """MeanFlow solver (R/s3gen.R:639-649): linear schedule, no CFG, the estimator sees (t, r) of every step."""
+    ts = np.linspace(0.0, 1.0, n_timesteps + 1).astype(F32)
+    x = z.astype(F32)
+    for step in range(len(ts) - 1):
+        t, r = ts[step:step + 1], ts[step + 1:step + 2]
+        d = est.forward(x, mask, mu, t, spks, cond, r=r)
+        x = (x + F32(r[0] - t[0]) * d).astype(F32)
+    return x

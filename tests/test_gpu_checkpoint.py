@@ -128,6 +128,7 @@ def test_packed_bf16_cache(tmp_path, variant):
     st6, f, _ = run(cache=True)
     assert st6 == _lib.CACHE_REPLACED and not np.array_equal(f[1], base[1])
     assert run(cache=True)[0] == _lib.CACHE_USED
+    base = f                                                 # the checkpoint now holds the second set of weights
     # a cache of ANOTHER checkpoint under this name is refused
     other = synth.write_safetensors(synth.synth_llama_weights(synth.TINY, 99) if variant == "llama" else
                                     synth.synth_turbo_weights(synth.TURBO_TINY, 99), str(tmp_path / "other.safetensors"))

@@ -1,0 +1,158 @@
+"""Pins oracle/s3gen_oracle.py op-for-op against CPU libtorch (python `torch`), the way tests/test_oracle_vs_torch.py pins the
+T3 oracle: the same sequence as R/s3gen.R:64-528 written with the ATen entry points R torch dispatches to (conv1d on a
+left-padded input, layer_norm, softplus + tanh, gelu(approximate = "tanh"), softmax, matmul), on a synthetic checkpoint in
+the key layout of load_cfm_estimator_weights (R/s3gen.R:1070-1178).  The reference holds no S3Gen fixture and its weights
+are not in the container: parity against the reference itself is UNPINNED (stated in the oracle's header and DESIGN.md)."""
+import numpy as np
+import pytest
+
+from chatterbox_amd import synth
+from oracle import s3gen_oracle as S
+
+torch = pytest.importorskip("torch")
+F = torch.nn.functional
+
+
+class TorchEstimator:
+    def __init__(self, w, dims, prefix=synth.CFM_PREFIX):
+        self.w = {k[len(prefix):]: torch.from_numpy(v) for k, v in w.items()}
+        self.d = dims
+
+    def temb(self, t):
+        half = self.d.time_in // 2
+        emb = torch.exp(torch.arange(half, dtype=torch.float32) * (-np.log(10000.0) / (half - 1)))
+        e = 1000 * t.unsqueeze(1) * emb.unsqueeze(0)
+        e = torch.cat([e.sin(), e.cos()], dim=-1)
+        w = self.w
+        e = F.linear(e, w["time_mlp.linear_1.weight"], w["time_mlp.linear_1.bias"])
+        return F.linear(F.silu(e), w["time_mlp.linear_2.weight"], w["time_mlp.linear_2.bias"])
+
+    def cconv(self, x, name):
+        k = self.w[name + ".weight"].shape[2]
+        return F.conv1d(F.pad(x, (k - 1, 0)), self.w[name + ".weight"], self.w[name + ".bias"])
+
+    def block(self, x, mask, p):
+        h = self.cconv(x * mask, p + "block.0").transpose(1, 2)
+        h = F.layer_norm(h, (h.shape[-1],), self.w[p + "block.2.weight"], self.w[p + "block.2.bias"]).transpose(1, 2)
+        return h * torch.tanh(F.softplus(h)) * mask
+
+    def resnet(self, x, mask, te, p):
+        h = self.block(x, mask, p + "block1.")
+        m = te * torch.tanh(F.softplus(te))
+        h = h + F.linear(m, self.w[p + "mlp.1.weight"], self.w[p + "mlp.1.bias"]).unsqueeze(-1)
+        h = self.block(h, mask, p + "block2.")
+        return h + F.conv1d(x * mask, self.w[p + "res_conv.weight"], self.w[p + "res_conv.bias"])
+
+    def tfm(self, x, p):
+        w, H, Dh = self.w, self.d.heads, self.d.head_dim
+        B, T, C = x.shape
+        n = F.layer_norm(x, (C,), w[p + "norm1.weight"], w[p + "norm1.bias"])
+        q, k, v = (F.linear(n, w[p + f"attn1.to_{c}.weight"]).view(B, T, H, Dh).transpose(1, 2) for c in "qkv")
+        a = torch.softmax(torch.matmul(q, k.transpose(-2, -1)) * Dh ** -0.5, dim=-1)
+        o = torch.matmul(a, v).transpose(1, 2).contiguous().view(B, T, -1)
+        x = x + F.linear(o, w[p + "attn1.to_out.0.weight"], w[p + "attn1.to_out.0.bias"])
+        n = F.layer_norm(x, (C,), w[p + "norm3.weight"], w[p + "norm3.bias"])
+        f = F.gelu(F.linear(n, w[p + "ff.net.0.proj.weight"], w[p + "ff.net.0.proj.bias"]), approximate="tanh")
+        return x + F.linear(f, w[p + "ff.net.2.weight"], w[p + "ff.net.2.bias"])
+
+    def forward(self, x, mask, mu, t, spks, cond, r=None):
+        te = self.temb(t)
+        if r is not None:
+            te = F.linear(torch.cat([te, self.temb(r)], dim=1), self.w["time_embed_mixer.weight"])
+        T = x.shape[2]
+        h = torch.cat([x, mu, spks.unsqueeze(2).expand(-1, -1, T), cond], dim=1)
+        h = self.resnet(h, mask, te, "down_blocks.0.0.").transpose(1, 2)
+        for i in range(self.d.n_tfm):
+            h = self.tfm(h, f"down_blocks.0.1.{i}.")
+        h = h.transpose(1, 2)
+        skip = h
+        h = self.cconv(h * mask, "down_blocks.0.2")
+        for m in range(self.d.n_mid):
+            h = self.resnet(h, mask, te, f"mid_blocks.{m}.0.").transpose(1, 2)
+            for j in range(self.d.n_tfm):
+                h = self.tfm(h, f"mid_blocks.{m}.1.{j}.")
+            h = h.transpose(1, 2)
+        h = self.resnet(torch.cat([h, skip], dim=1), mask, te, "up_blocks.0.0.").transpose(1, 2)
+        for i in range(self.d.n_tfm):
+            h = self.tfm(h, f"up_blocks.0.1.{i}.")
+        h = self.cconv(h.transpose(1, 2) * mask, "up_blocks.0.2")
+        h = self.block(h, mask, "final_block.")
+        return F.conv1d(h * mask, self.w["final_proj.weight"], self.w["final_proj.bias"])
+
+
+def _case(dims, T, seed, B=2):
+    w = synth.synth_cfm_weights(dims, 777)
+    mu, spks, cond, z = synth.synth_cfm_inputs(dims, T, seed, B)
+    mask = np.ones((B, 1, T), np.float32)
+    return w, mu, spks, cond, z, mask
+
+
+@pytest.mark.parametrize("dims,T", [(synth.CFM_TINY, 37), (synth.CfmDims(n_mid=1, n_tfm=1), 50)], ids=["tiny", "full-width"])
+def test_estimator_matches_libtorch(dims, T):
+    w, mu, spks, cond, z, mask = _case(dims, T, 3)
+    mask[1, 0, T - 5:] = 0.0                     # a padded tail in row 2: the mask multiplies, attention stays unmasked
+    t = np.array([0.3, 0.85], np.float32)
+    got = S.CfmEstimatorOracle(w, heads=dims.heads, head_dim=dims.head_dim, time_in=dims.time_in).forward(z, mask, mu, t, spks, cond)
+    te = TorchEstimator(w, dims)
+    with torch.no_grad():
+        want = te.forward(*(torch.from_numpy(a) for a in (z, mask, mu, t, spks, cond))).numpy()
+    assert got.shape == (2, dims.mel, T)
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_meanflow_mixer_matches_libtorch():
+    dims = synth.CfmDims(mel=16, hidden=64, n_mid=1, n_tfm=1, heads=2, time_in=64, time_dim=128, meanflow=True)
+    w, mu, spks, cond, z, mask = _case(dims, 21, 4, B=1)
+    t, r = np.array([0.0], np.float32), np.array([0.5], np.float32)
+    est = S.CfmEstimatorOracle(w, heads=2, head_dim=64, time_in=64)
+    assert est.meanflow
+    got = est.forward(z, mask, mu, t, spks, cond, r=r)
+    with torch.no_grad():
+        want = TorchEstimator(w, dims).forward(*(torch.from_numpy(a) for a in (z, mask, mu, t, spks, cond)), r=torch.from_numpy(r)).numpy()
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_euler_solver_matches_libtorch_loop():
+    """solve_euler (R/s3gen.R:651-751) restated in torch beside the oracle's: cosine schedule, CFG batch of two with
+    the second row's mu / spks / cond zeroed, (1 + 0.7) cond - 0.7 uncond, t accumulated step by step."""
+    dims = synth.CFM_TINY
+    w, mu, spks, cond, z, mask = _case(dims, 29, 9, B=1)
+    est = S.CfmEstimatorOracle(w, heads=dims.heads, head_dim=dims.head_dim, time_in=dims.time_in)
+    got = S.solve_euler(est, z, mu, mask, spks, cond, n_timesteps=10)
+    te = TorchEstimator(w, dims)
+    with torch.no_grad():
+        tz, tmu, tmask, tspk, tcond = (torch.from_numpy(a) for a in (z, mu, mask, spks, cond))
+        ts = torch.linspace(0, 1, 11, dtype=torch.float32)
+        ts = 1 - torch.cos(ts * 0.5 * np.pi)
+        x, t, dt = tz, ts[0].unsqueeze(0), ts[1] - ts[0]
+        for step in range(1, 11):
+            x_in = torch.cat([x, x]); m_in = torch.cat([tmask, tmask])
+            mu_in = torch.cat([tmu, torch.zeros_like(tmu)]); s_in = torch.cat([tspk, torch.zeros_like(tspk)])
+            c_in = torch.cat([tcond, torch.zeros_like(tcond)]); t_in = torch.cat([t, t])
+            d = te.forward(x_in, m_in, mu_in, t_in, s_in, c_in)
+            x = x + dt * ((1.0 + 0.7) * d[0:1] - 0.7 * d[1:2])
+            t = t + dt
+            if step < 10:
+                dt = ts[step + 1] - ts[step]
+        want = x.numpy()
+    assert np.isfinite(got).all() and np.abs(got - want).max() < 5e-5 * max(1.0, np.abs(want).max())
+    # the schedule itself: 0 at the start, 1 at the end, cosine spacing (finer steps first)
+    sp = S.t_span_cosine(10)
+    assert sp[0] == 0 and abs(sp[-1] - 1) < 1e-6 and np.all(np.diff(sp) > 0) and sp[1] - sp[0] < sp[-1] - sp[-2]
+
+
+def test_synthetic_checkpoint_has_the_loader_layout():
+    """Every key load_cfm_estimator_weights copies (R/s3gen.R:1092-1175) exists with the module's shape."""
+    d = synth.CFM_FULL
+    w = synth.synth_cfm_weights(d, 777)
+    p = synth.CFM_PREFIX
+    assert w[p + "time_mlp.linear_1.weight"].shape == (1024, 320)
+    assert w[p + "down_blocks.0.0.block1.block.0.weight"].shape == (256, 320, 3)
+    assert w[p + "down_blocks.0.0.res_conv.weight"].shape == (256, 320, 1)
+    assert w[p + "up_blocks.0.0.block1.block.0.weight"].shape == (256, 512, 3)
+    assert w[p + "mid_blocks.11.1.3.attn1.to_q.weight"].shape == (512, 256)
+    assert w[p + "mid_blocks.11.1.3.attn1.to_out.0.bias"].shape == (256,)
+    assert w[p + "mid_blocks.0.1.0.ff.net.0.proj.weight"].shape == (1024, 256)
+    assert w[p + "final_proj.weight"].shape == (80, 256, 1)
+    n_tfm = sum(1 for k in w if k.endswith("norm1.weight"))
+    assert n_tfm == 56 and sum(v.size for v in w.values()) > 60e6
