@@ -53,6 +53,11 @@ class Cond(C.Structure):
                 ("emotion_adv", C.c_float), ("has_emotion_adv", C.c_int32)]
 
 
+class CfmInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("mel", "hidden", "n_mid", "n_tfm", "heads", "head_dim", "d_ff", "time_in", "time_dim",
+                                         "meanflow", "device", "reserved_")] + [("weight_bytes", C.c_int64)]
+
+
 class KStat(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_int32), ("total_us", C.c_float),
                 ("bytes", C.c_double)]
@@ -98,6 +103,11 @@ SYMBOLS = {
     "t3mi_session_profile_step": (C.c_int, [_H, C.POINTER(KStat), C.c_int, C.POINTER(C.c_int)]),
     "t3mi_session_end": (C.c_int, [_H]),
     "t3mi_stream": (C.c_void_p, [_H]),
+    "t3mi_cfm_open": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(_H)]),
+    "t3mi_cfm_close": (C.c_int, [_H]),
+    "t3mi_cfm_get_info": (C.c_int, [_H, C.POINTER(CfmInfo)]),
+    "t3mi_cfm_estimator": (C.c_int, [_H, C.c_int, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
+    "t3mi_cfm_solve": (C.c_int, [_H, C.c_int, _FP, _FP, _FP, _FP, _FP, C.c_int, C.c_double, C.c_int, _FP, _FP]),
 }
 
 _lib = None

@@ -1,0 +1,27 @@
+// Launch wrappers of the CFM-estimator kernels (cfm_kernels.hip); the GEMMs are launch_gemm's (kernels.hpp).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+
+namespace t3k {
+
+// cfm_attention (R/s3gen.R:260-290) without mask: qkv [n_seq * T][3 * heads * 64] (q | k | v), out [n_seq * T][heads * 64]
+hipError_t launch_cfm_attn(const float* qkv, float* out, int n_seq, int T, int heads, int head_dim, hipStream_t s);
+// out[m] = mish(LayerNorm_C(in[m])) * mask[m] (+ add[m / T][0 .. C))     (causal_block1d, R/s3gen.R:186-196, :227)
+hipError_t launch_cfm_norm_mish(const float* in, const float* w, const float* b, const float* mask, const float* add, int add_ld,
+                                float* out, int M, int C, int T, float eps, hipStream_t s);
+// col[m][k * C + c] = (x * mask)[m - 2 + k][c] within the row's sequence of T rows, zero before its start; masked
+// (optional) = x * mask                                                     (causal_conv1d, R/s3gen.R:135-141)
+hipError_t launch_cfm_window3(const float* x, const float* mask, float* col, float* masked, int M, int C, int T, hipStream_t s);
+hipError_t launch_cfm_concat(const float* a, int Ca, const float* b, int Cb, float* out, int M, hipStream_t s);
+hipError_t launch_cfm_mask_rows(const float* x, const float* mask, float* out, int M, int C, hipStream_t s);
+// mode 0 silu, 1 mish
+hipError_t launch_cfm_act(const float* x, float* out, size_t n, int mode, hipStream_t s);
+// sinusoidal_pos_emb (R/s3gen.R:72-91): t [B] on device -> out [B][dim]
+hipError_t launch_cfm_time_sin(const float* t, float* out, int B, int dim, float scale, hipStream_t s);
+// x += dt * (one_plus_rate * d_cond - rate * d_uncond)   (R/s3gen.R:734-737);  d_uncond == nullptr: x += dt * d_cond (:644-646)
+hipError_t launch_cfm_euler(float* x, const float* d_cond, const float* d_uncond, size_t n, float dt, float one_plus_rate, float rate,
+                            hipStream_t s);
+
+}  // namespace t3k

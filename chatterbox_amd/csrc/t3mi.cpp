@@ -140,6 +140,9 @@ struct Session {
 
 }  // namespace
 
+// the error text of this thread, for the other translation units of the library (cfm.cpp)
+int t3mi_set_error(int code, const std::string& msg) { return fail(code, msg); }
+
 struct t3mi_model {
     int device = 0, variant = 0, wdtype = 0;
     int n_layers = 0, d = 0, H = 0, F = 0, V = 0, max_pos = 0;

@@ -1,0 +1,99 @@
+"""Host-side mirror of the reference's S3Gen flow decoder interface over the t3mi_cfm_* C ABI (first piece).
+
+`CfmEstimator` stands for `cfm_estimator` with `load_cfm_estimator_weights` applied (R/s3gen.R:389-528, 1070-1178):
+`forward(x, mask, mu, t, spks, cond, r = None)` keeps the reference's argument order and (B, 80, T) layouts.
+`causal_cfm_forward` is `causal_cfm$forward` (R/s3gen.R:594-636): cosine schedule + solve_euler with classifier-free
+guidance, or the linear schedule + basic_euler of a meanflow model.  There is no CPU fallback: the arithmetic runs in
+libt3mi.so's gfx950 kernels or not at all."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["CfmEstimator", "load_cfm_estimator", "causal_cfm_forward"]
+
+_FP = C.POINTER(C.c_float)
+
+
+def _f32(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_FP)
+
+
+class CfmEstimator:
+    """Weights of the CFM estimator resident on one MI355X (read from the unchanged s3gen safetensors file)."""
+
+    def __init__(self, path: str, device: int = 0, prefix: str = "flow.decoder.estimator.", n_heads: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.t3mi_cfm_open(path.encode(), prefix.encode(), int(device), int(n_heads), C.byref(h)))
+        self._h = h
+        info = _lib.CfmInfo()
+        _lib.check(self._lib.t3mi_cfm_get_info(self._h, C.byref(info)))
+        self.info = info
+        self.mel, self.meanflow = int(info.mel), bool(info.meanflow)
+
+    def forward(self, x, mask, mu, t, spks, cond, r=None) -> np.ndarray:
+        """cfm_estimator$forward (R/s3gen.R:446-520).  x, mu, cond (B, mel, T); mask (B, 1, T); t, r [B]; spks (B, mel)."""
+        x = _f32(x)
+        B, mel, T = x.shape
+        mask, mu, cond = _f32(mask, (B, 1, T)), _f32(mu, (B, mel, T)), _f32(cond, (B, mel, T))
+        t, spks = _f32(np.reshape(t, -1), (B,)), _f32(spks, (B, mel))
+        rr = None if r is None else _f32(np.reshape(r, -1), (B,))
+        out = np.empty((B, mel, T), dtype=np.float32)
+        _lib.check(self._lib.t3mi_cfm_estimator(self._h, B, T, _p(x), _p(mask), _p(mu), _p(t), _p(spks), _p(cond), _p(rr), _p(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.t3mi_cfm_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def load_cfm_estimator(path: str, device: int = 0, **kw) -> CfmEstimator:
+    return CfmEstimator(path, device, **kw)
+
+
+def causal_cfm_forward(estimator: CfmEstimator, mu, mask, spks, cond, noise, n_timesteps: int = 10, temperature: float = 1.0,
+                       inference_cfg_rate: float = 0.7, meanflow: Optional[bool] = None, timing: Optional[dict] = None) -> np.ndarray:
+    """causal_cfm$forward(mu, mask, spks, cond, n_timesteps, temperature, ...) (R/s3gen.R:594-636), one utterance, untraced.
+    `noise` (1, mel, >= T) plays the part of the reference's own `rand_noise` buffer (standard model: `noise[:, :, :T] *
+    temperature`, :616-619) or of `torch_randn_like(mu)` with `noised_mels` already laid over it (meanflow, :610-615).
+    Returns the mel (1, mel, T).  timing: a dict that receives {"device_ms": ...}."""
+    mu = _f32(mu)
+    _, mel, T = mu.shape
+    use_mf = estimator.meanflow if meanflow is None else bool(meanflow)
+    z = _f32(noise)[:, :, :T]
+    if not use_mf:
+        z = z * np.float32(temperature)
+    z = _f32(z, (1, mel, T))
+    mask, spks, cond = _f32(mask, (1, 1, T)), _f32(spks, (1, mel)), _f32(cond, (1, mel, T))
+    out = np.empty((1, mel, T), dtype=np.float32)
+    ms = C.c_float(0)
+    _lib.check(estimator._lib.t3mi_cfm_solve(estimator._h, T, _p(z), _p(mu), _p(mask), _p(spks), _p(cond), int(n_timesteps),
+                                             float(inference_cfg_rate), 1 if use_mf else 0, _p(out), C.byref(ms)))
+    if timing is not None:
+        timing["device_ms"] = float(ms.value)
+    return out

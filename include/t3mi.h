@@ -236,6 +236,35 @@ int t3mi_session_end(t3mi_model* m);
 /* Raw HIP stream of the handle (hipStream_t as void*), for callers that time with their own events. */
 void* t3mi_stream(t3mi_model* m);
 
+/* ---- S3Gen flow-matching decoder: the CFM estimator and its Euler solvers (first piece) -------------------
+ * What generate() runs on T3's speech tokens after the conformer encoder (R/tts.R:392-398 -> s3gen$inference R/s3gen.R:987-1056
+ * -> causal_masked_diff_xvec$forward :805-890 -> causal_cfm$forward :594-636).  Sequences use the reference's layouts:
+ * (B, 80, T) float32 row-major, mask (B, 1, T), spks (B, 80), t / r [B].  fp32 arithmetic (exact-fp32 MFMA GEMMs). */
+typedef struct t3mi_cfm t3mi_cfm;
+typedef struct t3mi_cfm_info {
+    int32_t mel, hidden, n_mid, n_tfm, heads, head_dim, d_ff, time_in, time_dim, meanflow, device, reserved_;
+    int64_t weight_bytes;
+} t3mi_cfm_info;
+/* cfm_estimator(...) + load_cfm_estimator_weights (R/s3gen.R:389-444, 1070-1178): reads the estimator's tensors from the
+ * UNCHANGED s3gen safetensors file under `prefix` (NULL = "flow.decoder.estimator.", R/s3gen.R:1231); shapes come from the
+ * file; a `time_embed_mixer.weight` makes it a meanflow estimator (R/s3gen.R:404-413).  n_heads: 0 = inner / 64. */
+int t3mi_cfm_open(const char* safetensors_path, const char* prefix, int device, int n_heads, t3mi_cfm** out);
+int t3mi_cfm_close(t3mi_cfm* m);
+int t3mi_cfm_get_info(const t3mi_cfm* m, t3mi_cfm_info* info);
+/* cfm_estimator$forward(x, mask, mu, t, spks, cond, r) (R/s3gen.R:446-520): host arrays in, out (B, 80, T).  r = NULL unless
+ * the model is a meanflow one.  Attention is unmasked (compute_attn_mask returns NULL, :522-527); the mask multiplies. */
+int t3mi_cfm_estimator(t3mi_cfm* m, int B, int T, const float* x, const float* mask, const float* mu, const float* t,
+                       const float* spks, const float* cond, const float* r, float* out);
+/* causal_cfm$forward (R/s3gen.R:594-636) for one utterance, untraced: z (1, 80, T) is the start noise the reference takes
+ * from its own torch_randn buffer (`rand_noise[,, 1:T] * temperature`, :616-619; meanflow: randn with `noised_mels` laid over
+ * the generated part, :610-615) -- libtorch's stream cannot be reproduced, so the caller owns it.  meanflow = 0: cosine
+ * schedule and solve_euler (:651-751) with classifier-free guidance as a batch of two (row 2: mu / spks / cond zero),
+ * d = (1 + cfg_rate) d_cond - cfg_rate d_uncond (0.7 in the reference, :554), t accumulated in float32.  meanflow = 1:
+ * linear schedule and basic_euler (:639-649), no guidance, the estimator sees (t, r).  out (1, 80, T).  device_ms (may be
+ * NULL): HIP-event time of the n_timesteps estimator calls and Euler updates on the handle's stream. */
+int t3mi_cfm_solve(t3mi_cfm* m, int T, const float* z, const float* mu, const float* mask, const float* spks, const float* cond,
+                   int n_timesteps, double cfg_rate, int meanflow, float* out, float* device_ms);
+
 #ifdef __cplusplus
 }
 #endif

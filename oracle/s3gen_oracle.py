@@ -194,9 +194,17 @@ class CfmEstimatorOracle:
         return causal_conv1d(h * mask, w["final_proj.weight"], w["final_proj.bias"])      # :517 (1 x 1)
 
 
+def linspace_f32(n_timesteps: int) -> np.ndarray:
+    """torch_linspace(0, 1, n + 1, dtype = float32) as ATen computes it on the CPU: step = 1 / n in float32, the first
+    half counted up from the start, the second half counted down from the end."""
+    n = n_timesteps
+    step = F32(1) / F32(n)
+    return np.array([F32(i) * step if i < (n + 1) // 2 else F32(1) - F32(n - i) * step for i in range(n + 1)], dtype=F32)
+
+
 def t_span_cosine(n_timesteps: int) -> np.ndarray:
     """R/s3gen.R:622-625: linspace(0, 1, n + 1) in float32, then 1 - cos(t * 0.5 * pi)."""
-    ts = np.linspace(0.0, 1.0, n_timesteps + 1).astype(F32)
+    ts = linspace_f32(n_timesteps)
     return (F32(1) - np.cos((ts * F32(0.5)).astype(F32) * F32(math.pi), dtype=F32)).astype(F32)
 
 
@@ -229,7 +237,7 @@ def solve_euler(est: CfmEstimatorOracle, z, mu, mask, spks, cond, n_timesteps: i
 
 def basic_euler(est: CfmEstimatorOracle, z, mu, mask, spks, cond, n_timesteps: int = 2) -> np.ndarray:
     """MeanFlow solver (R/s3gen.R:639-649): linear schedule, no CFG, the estimator sees (t, r) of every step."""
-    ts = np.linspace(0.0, 1.0, n_timesteps + 1).astype(F32)
+    ts = linspace_f32(n_timesteps)
     x = z.astype(F32)
     for step in range(len(ts) - 1):
         t, r = ts[step:step + 1], ts[step + 1:step + 2]

@@ -1,0 +1,126 @@
+"""SURVEY §8 f4, first closed piece: the CFM estimator (R/s3gen.R:389-528) and causal_cfm's Euler solvers (:594-751) on the
+GPU through the C ABI (t3mi_cfm_*), against the numpy oracle (oracle/s3gen_oracle.py, pinned op-for-op to CPU libtorch in
+tests/test_s3gen_oracle_vs_torch.py) on synthetic checkpoints in the key layout of load_cfm_estimator_weights
+(R/s3gen.R:1070-1178).  The reference ships no S3Gen fixture and its weights are absent: parity against the reference
+itself is UNPINNED; what is shown is GPU == oracle.
+
+Bar (fp32 arithmetic on both sides, other summation orders): one estimator call and the whole solve within 1e-3 of the
+largest output magnitude; observed ~1e-5."""
+import numpy as np
+import pytest
+
+import chatterbox_amd as cb
+from chatterbox_amd import _lib, synth
+from oracle import s3gen_oracle as S
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+def _rel(a, b):
+    return float(np.abs(a.astype(np.float64) - b).max() / np.abs(b).max())
+
+
+def _oracle(dims, w):
+    return S.CfmEstimatorOracle(w, heads=dims.heads, head_dim=dims.head_dim, time_in=dims.time_in)
+
+
+@pytest.mark.parametrize("dims,T,B", [(synth.CFM_TINY, 37, 2), (synth.CFM_TINY, 150, 3), (synth.CfmDims(n_mid=1, n_tfm=2), 70, 2)],
+                         ids=["tiny-37", "tiny-150x3", "full-width-70"])
+def test_estimator_call_matches_the_oracle(dims, T, B):
+    """One cfm_estimator$forward: B sequences, a padded tail in the last one (the mask multiplies; attention stays unmasked,
+    R/s3gen.R:522-527), different t per row; T not a multiple of any tile."""
+    w = synth.synth_cfm_weights(dims, 777)
+    mu, spks, cond, z = synth.synth_cfm_inputs(dims, T, 3, B)
+    mask = np.ones((B, 1, T), np.float32)
+    mask[B - 1, 0, T - 6:] = 0.0
+    t = np.linspace(0.1, 0.9, B).astype(np.float32)
+    want = _oracle(dims, w).forward(z, mask, mu, t, spks, cond)
+    with cb.load_cfm_estimator(synth.ensure_cfm_checkpoint(dims, 777)) as est:
+        assert (est.info.mel, est.info.hidden, est.info.n_mid, est.info.n_tfm, est.info.heads) == \
+            (dims.mel, dims.hidden, dims.n_mid, dims.n_tfm, dims.heads)
+        got = est.forward(z, mask, mu, t, spks, cond)
+        again = est.forward(z, mask, mu, t, spks, cond)
+    assert got.shape == want.shape and np.isfinite(got).all()
+    assert _rel(got, want) < TOL, _rel(got, want)
+    assert np.array_equal(got, again)            # fixed summation orders: bit-reproducible
+
+
+def test_full_size_estimator_call_matches_the_oracle():
+    """The real shapes (320 -> 256, 12 mid blocks, 56 transformer blocks of 8 x 64, R/s3gen.R:392-444) at T = 96, CFG pair."""
+    dims = synth.CFM_FULL
+    T = 96
+    w = synth.synth_cfm_weights(dims, 777)
+    mu, spks, cond, z = synth.synth_cfm_inputs(dims, T, 5, 1)
+    x_in = np.concatenate([z, z]); mu_in = np.concatenate([mu, np.zeros_like(mu)])
+    sp_in = np.concatenate([spks, np.zeros_like(spks)]); c_in = np.concatenate([cond, np.zeros_like(cond)])
+    mask = np.ones((2, 1, T), np.float32)
+    t = np.array([0.37, 0.37], np.float32)
+    want = _oracle(dims, w).forward(x_in, mask, mu_in, t, sp_in, c_in)
+    with cb.load_cfm_estimator(synth.ensure_cfm_checkpoint(dims, 777)) as est:
+        assert est.info.weight_bytes > 250e6
+        got = est.forward(x_in, mask, mu_in, t, sp_in, c_in)
+    assert _rel(got, want) < TOL, _rel(got, want)
+
+
+@pytest.mark.parametrize("dims,T,steps", [(synth.CFM_TINY, 53, 10), (synth.CfmDims(n_mid=2, n_tfm=1), 40, 10), (synth.CFM_TINY, 20, 3)],
+                         ids=["tiny-10", "full-width-10", "tiny-3"])
+def test_euler_solve_matches_the_oracle(dims, T, steps):
+    """causal_cfm$forward + solve_euler (R/s3gen.R:594-636, 651-751): cosine schedule, CFG batch of two with rate 0.7,
+    t accumulated in float32 -- the whole 10-step solve against the oracle's."""
+    w = synth.synth_cfm_weights(dims, 777)
+    mu, spks, cond, z = synth.synth_cfm_inputs(dims, T, 11, 1)
+    mask = np.ones((1, 1, T), np.float32)
+    want = S.solve_euler(_oracle(dims, w), z, mu, mask, spks, cond, n_timesteps=steps)
+    tm = {}
+    with cb.load_cfm_estimator(synth.ensure_cfm_checkpoint(dims, 777)) as est:
+        got = cb.causal_cfm_forward(est, mu, mask, spks, cond, noise=z, n_timesteps=steps, timing=tm)
+        # `temperature` scales the reference's noise buffer (R/s3gen.R:618): the same as handing over the scaled noise
+        half = cb.causal_cfm_forward(est, mu, mask, spks, cond, noise=z, n_timesteps=steps, temperature=0.5)
+        half2 = cb.causal_cfm_forward(est, mu, mask, spks, cond, noise=z * np.float32(0.5), n_timesteps=steps)
+    assert got.shape == (1, dims.mel, T) and np.isfinite(got).all() and tm["device_ms"] > 0
+    assert _rel(got, want) < TOL, _rel(got, want)
+    assert np.array_equal(half, half2) and not np.array_equal(half, got)
+
+
+def test_meanflow_basic_euler_matches_the_oracle():
+    """Turbo's S3Gen (meanflow = TRUE, n_cfm_timesteps = 2, R/tts.R / R/s3gen.R:1016-1023): time_embed_mixer over (t, r),
+    linear schedule, basic_euler without guidance (R/s3gen.R:639-649)."""
+    dims = synth.CfmDims(mel=16, hidden=64, n_mid=2, n_tfm=1, heads=2, time_in=64, time_dim=128, meanflow=True)
+    T = 45
+    w = synth.synth_cfm_weights(dims, 778)
+    mu, spks, cond, z = synth.synth_cfm_inputs(dims, T, 12, 1)
+    mask = np.ones((1, 1, T), np.float32)
+    orc = _oracle(dims, w)
+    want = S.basic_euler(orc, z, mu, mask, spks, cond, n_timesteps=2)
+    with cb.load_cfm_estimator(synth.ensure_cfm_checkpoint(dims, 778)) as est:
+        assert est.meanflow
+        t, r = np.array([0.25], np.float32), np.array([0.75], np.float32)
+        one = est.forward(z, mask, mu, t, spks, cond, r=r)
+        got = cb.causal_cfm_forward(est, mu, mask, spks, cond, noise=z, n_timesteps=2)
+    assert _rel(one, orc.forward(z, mask, mu, t, spks, cond, r=r)) < TOL
+    assert _rel(got, want) < TOL, _rel(got, want)
+
+
+def test_cfm_rejects_bad_input(tmp_path):
+    dims = synth.CFM_TINY
+    path = synth.ensure_cfm_checkpoint(dims, 777)
+    with cb.load_cfm_estimator(path) as est:
+        mu, spks, cond, z = synth.synth_cfm_inputs(dims, 8, 1, 1)
+        mask = np.ones((1, 1, 8), np.float32)
+        with pytest.raises(_lib.T3miError) as e:      # r on a model without the mixer
+            est.forward(z, mask, mu, np.array([0.5], np.float32), spks, cond, r=np.array([0.7], np.float32))
+        assert e.value.code == _lib.ERR_ARG
+        with pytest.raises(_lib.T3miError) as e:
+            cb.causal_cfm_forward(est, mu, mask, spks, cond, noise=z, n_timesteps=0)
+        assert e.value.code == _lib.ERR_ARG
+    with pytest.raises(_lib.T3miError) as e:          # a T3 checkpoint is not an S3Gen one
+        cb.load_cfm_estimator(synth.ensure_checkpoint(synth.TINY, 1234))
+    assert e.value.code == _lib.ERR_IO
+    w = synth.synth_cfm_weights(dims, 777)
+    del w[synth.CFM_PREFIX + "mid_blocks.1.1.0.ff.net.2.bias"]
+    bad = synth.write_safetensors(w, str(tmp_path / "missing.safetensors"))
+    with pytest.raises(_lib.T3miError) as e:
+        cb.load_cfm_estimator(bad)
+    assert e.value.code == _lib.ERR_IO and "ff.net.2.bias" in str(e.value)

@@ -137,6 +137,8 @@ def test_euler_solver_matches_libtorch_loop():
         want = x.numpy()
     assert np.isfinite(got).all() and np.abs(got - want).max() < 5e-5 * max(1.0, np.abs(want).max())
     # the schedule itself: 0 at the start, 1 at the end, cosine spacing (finer steps first)
+    for n in (1, 2, 3, 7, 10, 32):     # the float32 linspace itself, bit for bit
+        assert np.array_equal(S.linspace_f32(n), torch.linspace(0, 1, n + 1, dtype=torch.float32).numpy()), n
     sp = S.t_span_cosine(10)
     assert sp[0] == 0 and abs(sp[-1] - 1) < 1e-6 and np.all(np.diff(sp) > 0) and sp[1] - sp[0] < sp[-1] - sp[-2]
 
