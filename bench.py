@@ -509,6 +509,15 @@ def run(args, world, rank, local_rank):
             except Exception as e:
                 attach["turbo8_error"] = f"{type(e).__name__}: {e}"
 
+        if world == 1:
+            # SURVEY §8 f4, first piece: the S3Gen flow decoder's 10-step CFG solve on the full-size CFM estimator (fp32)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                import bench_cfm
+                attach["cfm_solve"] = bench_cfm.run(frames=500, steps=10, reps=3)
+            except Exception as e:
+                attach["cfm_solve_error"] = f"{type(e).__name__}: {e}"
+
     if rank == 0:
         cpu = None
         if world == 1 and args.cpu_steps > 0:

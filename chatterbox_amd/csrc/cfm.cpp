@@ -85,6 +85,8 @@ struct t3mi_cfm {
     std::vector<Tfm> tfms;             // down (n_tfm), mid (n_mid * n_tfm), up (n_tfm)
     // workspace of the current (B, T)
     Buf h0, col, xa, xb, xn, xm, qkv, ao, ffb, skip, cat, dout, tsin, temb, temb2, tact, tadd, tcur, mask, xrows, stat, ttab;
+    Buf apo, apml;      // attention key-split partials (launch_cfm_attn)
+    Buf gpart;          // K-split partial slabs of the GEMMs with few feature tiles (launch_gemm's `part`)
     size_t ws_rows = 0;
     int ws_B = 0;
 };
@@ -272,6 +274,10 @@ int gemm(t3mi_cfm* m, const float* A, const Lin& l, int M, int epi, float* y, co
     t3k::GemmArgs a;
     a.W = l.w; a.A = A; a.M = M; a.N = l.N; a.K = l.K; a.bias = l.b;
     a.y = y; a.resid = resid; a.ldy = l.N; a.yact = yact;
+    if (l.N <= m->C && M >= 64) {   // few feature tiles (N = hidden or mel): K split over blocks, folded by launch_gemm in a fixed order
+        a.part = m->gpart.f();
+        a.part_floats = m->gpart.bytes / 4;
+    }
     HIPCHK(t3k::launch_gemm(a, epi, 0, m->stream));
     return T3MI_OK;
 }
@@ -291,6 +297,9 @@ int ensure_ws(t3mi_cfm* m, int B, int T) {
     HIPCHK(m->xm.need(rows * cmax * 4));
     HIPCHK(m->qkv.need(rows * 3 * m->inner * 4));
     HIPCHK(m->ao.need(rows * m->inner * 4));
+    HIPCHK(m->apo.need((size_t)t3k::kCfmAttnMaxSplit * rows * m->inner * 4));
+    HIPCHK(m->apml.need((size_t)t3k::kCfmAttnMaxSplit * rows * m->heads * 2 * 4));
+    HIPCHK(m->gpart.need((size_t)16 * rows * C * 4));
     HIPCHK(m->ffb.need(rows * m->ff * 4));
     HIPCHK(m->skip.need(rows * C * 4));
     HIPCHK(m->cat.need(rows * 2 * C * 4));
@@ -333,7 +342,7 @@ int transformer(t3mi_cfm* m, const Tfm& t, float* x, int B, int T) {
     HIPCHK(t3k::launch_layernorm_rows(x, t.n1.w, t.n1.b, 1e-5f, m->xn.p, M, C, 0, m->stream));
     int rc = gemm(m, m->xn.f(), t.qkv, M, t3k::EPI_STORE, m->qkv.f(), nullptr, nullptr);
     if (rc) return rc;
-    HIPCHK(t3k::launch_cfm_attn(m->qkv.f(), m->ao.f(), B, T, m->heads, 64, m->stream));
+    HIPCHK(t3k::launch_cfm_attn(m->qkv.f(), m->ao.f(), B, T, m->heads, 64, m->apo.f(), m->apml.f(), m->stream));
     if ((rc = gemm(m, m->ao.f(), t.out, M, t3k::EPI_RESID, x, x, nullptr))) return rc;
     HIPCHK(t3k::launch_layernorm_rows(x, t.n3.w, t.n3.b, 1e-5f, m->xn.p, M, C, 0, m->stream));
     if ((rc = gemm(m, m->xn.f(), t.ff1, M, t3k::EPI_GELU, nullptr, nullptr, m->ffb.f()))) return rc;

@@ -35,16 +35,22 @@ __device__ __forceinline__ float mish_f(float x) {
 //                   a free permutation of the keys, so step r of key tile kt takes keys {16 kt + 4 g + r}: exactly the
 //                   C-layout register r of lane group g.  No transposition through LDS.
 // v_mfma_f32_16x16x4_f32 throughout: exact fp32 products, fp32 accumulate.
+// Keys split over blocks (n_split > 1) when the (query group, head, sequence) count alone would leave SIMDs idle -- a
+// 16-query wave is the unit of work and a 500-frame CFG pair has only 512 of them for 1024 SIMDs: split `sp` takes key
+// tiles [sp * tps, (sp + 1) * tps) and leaves an unnormalised partial (o, running max, sum) that cfm_attn_merge_kernel
+// combines in a fixed order; n_split == 1 writes the normalised rows directly.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void cfm_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int ld,
-                                                           int inner, float scale) {
+                                                           int inner, float scale, int n_split, int tps, float* __restrict__ po,
+                                                           float* __restrict__ pml, int M_total) {
     __shared__ __attribute__((aligned(16))) float kt_s[64 * kLd];
     __shared__ __attribute__((aligned(16))) float vt_s[64 * kLd];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = lane & 15, g = lane >> 4;
     const int head = blockIdx.y, seq = blockIdx.z;
     const size_t row0 = (size_t)seq * T;
-    const int q_lo = (blockIdx.x * NW + wave) * 16;
+    const int qblk = blockIdx.x / n_split, sp = blockIdx.x % n_split;
+    const int q_lo = (qblk * NW + wave) * 16;
     const int qi = min(q_lo + nl, T - 1);
     const float* qp = qkv + (row0 + qi) * ld + head * kDh + 4 * g;
     f32x4 qv[4];   // native vectors: arrays of HIP's float4 struct can end up in scratch memory
@@ -55,7 +61,7 @@ __global__ __launch_bounds__(64 * NW) void cfm_attn_kernel(const float* __restri
 
     constexpr int PF = 1024 / (64 * NW);   // float4 per thread per tile (64 keys x 16 float4)
     f32x4 pk[PF], pv[PF];
-    const int n_tiles = (T + 63) / 64;
+    const int j_lo = sp * tps, n_tiles = min((T + 63) / 64, j_lo + tps);   // this split's tiles [j_lo, n_tiles)
     auto prefetch = [&](int j) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
@@ -69,8 +75,8 @@ __global__ __launch_bounds__(64 * NW) void cfm_attn_kernel(const float* __restri
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    prefetch(0);
-    for (int j = 0; j < n_tiles; ++j) {
+    prefetch(j_lo);
+    for (int j = j_lo; j < n_tiles; ++j) {
         __syncthreads();   // the previous tile's reads are done
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(64 * NW) void cfm_attn_kernel(const float* __restri
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);      // finite from the first tile on (key 0 is always valid)
+        const float m_new = fmaxf(m_run, mx);      // finite from the first tile on (a split's first tile holds a valid key)
         const float alpha = expf(m_run - m_new);
         float ls = 0.f;
 #pragma unroll
@@ -132,11 +138,47 @@ __global__ __launch_bounds__(64 * NW) void cfm_attn_kernel(const float* __restri
             }
     }
     if (q_lo + nl < T) {
-        const float inv = 1.0f / l_run;
-        float* op = out + (row0 + q_lo + nl) * inner + head * kDh + 4 * g;
+        const size_t row = row0 + q_lo + nl;
+        if (n_split == 1) {
+            const float inv = 1.0f / l_run;
+            float* op = out + row * inner + head * kDh + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            *reinterpret_cast<float4*>(op + 16 * dt) = float4{o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<float4*>(op + 16 * dt) = float4{o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+        } else {
+            float* op = po + ((size_t)sp * M_total + row) * inner + head * kDh + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<float4*>(op + 16 * dt) = float4{o[dt][0], o[dt][1], o[dt][2], o[dt][3]};
+            if (g == 0) {
+                float* ml = pml + (((size_t)sp * M_total + row) * (inner / kDh) + head) * 2;
+                ml[0] = m_run;
+                ml[1] = l_run;
+            }
+        }
+    }
+}
+
+// out[row][head][d] = sum_s po[s] * exp(m_s - m) / sum_s l_s * exp(m_s - m), s ascending: one thread per 4 output values
+__global__ __launch_bounds__(256) void cfm_attn_merge_kernel(const float* __restrict__ po, const float* __restrict__ pml,
+                                                             float* __restrict__ out, int M, int inner, int n_split) {
+    const int H = inner / kDh, q4 = inner >> 2;
+    const size_t total = (size_t)M * q4;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t row = e / q4;
+        const int c4 = (int)(e % q4) << 2, head = c4 / kDh;
+        float mx = -INFINITY;
+        for (int s = 0; s < n_split; ++s) mx = fmaxf(mx, pml[(((size_t)s * M + row) * H + head) * 2]);
+        float l = 0.f;
+        float4 acc{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < n_split; ++s) {
+            const float* ml = pml + (((size_t)s * M + row) * H + head) * 2;
+            const float w = expf(ml[0] - mx);
+            l += ml[1] * w;
+            const float4 v = *reinterpret_cast<const float4*>(po + ((size_t)s * M + row) * inner + c4);
+            acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
+        }
+        const float inv = 1.0f / l;
+        *reinterpret_cast<float4*>(out + row * inner + c4) = float4{acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv};
     }
 }
 
@@ -272,14 +314,37 @@ inline int grid_for(size_t n) {
 
 }  // namespace
 
-hipError_t launch_cfm_attn(const float* qkv, float* out, int n_seq, int T, int heads, int head_dim, hipStream_t s) {
+int cfm_attn_splits(int n_seq, int T, int heads) {
+    // 16-query waves of the launch without a key split; aim at two waves per SIMD (2048), at most kCfmAttnMaxSplit splits,
+    // every split at least one 64-key tile
+    const long long waves = (long long)((T + 15) / 16) * heads * n_seq;
+    const int n_tiles = (T + 63) / 64;
+    int want = (int)((2048 + waves - 1) / waves);
+    want = want < 1 ? 1 : (want > kCfmAttnMaxSplit ? kCfmAttnMaxSplit : want);
+    want = want > n_tiles ? n_tiles : want;
+    const int tps = (n_tiles + want - 1) / want;
+    return (n_tiles + tps - 1) / tps;
+}
+
+hipError_t launch_cfm_attn(const float* qkv, float* out, int n_seq, int T, int heads, int head_dim, float* part_o, float* part_ml,
+                           hipStream_t s) {
     if (!qkv || !out || n_seq <= 0 || T <= 0 || heads <= 0 || head_dim != kDh) return hipErrorInvalidValue;
-    const int inner = heads * kDh, ld = 3 * inner;
+    const int inner = heads * kDh, ld = 3 * inner, M = n_seq * T;
     const float scale = 1.0f / sqrtf((float)head_dim);
+    const int n_tiles = (T + 63) / 64;
+    int ns = (part_o != nullptr && part_ml != nullptr) ? cfm_attn_splits(n_seq, T, heads) : 1;
+    const int tps = (n_tiles + ns - 1) / ns;
     // 16 NW queries per block: the narrower block when the wider one would leave CUs idle
-    const long long blocks4 = (long long)((T + 63) / 64) * heads * n_seq;
-    if (blocks4 >= 256) hipLaunchKernelGGL(cfm_attn_kernel<4>, dim3((T + 63) / 64, heads, n_seq), dim3(256), 0, s, qkv, out, T, ld, inner, scale);
-    else hipLaunchKernelGGL(cfm_attn_kernel<2>, dim3((T + 31) / 32, heads, n_seq), dim3(128), 0, s, qkv, out, T, ld, inner, scale);
+    const long long blocks4 = (long long)((T + 63) / 64) * heads * n_seq * ns;
+    if (blocks4 >= 512)
+        hipLaunchKernelGGL(cfm_attn_kernel<4>, dim3(((T + 63) / 64) * ns, heads, n_seq), dim3(256), 0, s, qkv, out, T, ld, inner, scale, ns, tps,
+                           part_o, part_ml, M);
+    else
+        hipLaunchKernelGGL(cfm_attn_kernel<2>, dim3(((T + 31) / 32) * ns, heads, n_seq), dim3(128), 0, s, qkv, out, T, ld, inner, scale, ns, tps,
+                           part_o, part_ml, M);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || ns == 1) return e;
+    hipLaunchKernelGGL(cfm_attn_merge_kernel, dim3(grid_for((size_t)M * (inner >> 2))), dim3(256), 0, s, part_o, part_ml, out, M, inner, ns);
     return hipGetLastError();
 }
 

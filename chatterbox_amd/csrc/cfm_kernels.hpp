@@ -6,8 +6,12 @@
 
 namespace t3k {
 
-// cfm_attention (R/s3gen.R:260-290) without mask: qkv [n_seq * T][3 * heads * 64] (q | k | v), out [n_seq * T][heads * 64]
-hipError_t launch_cfm_attn(const float* qkv, float* out, int n_seq, int T, int heads, int head_dim, hipStream_t s);
+// cfm_attention (R/s3gen.R:260-290) without mask: qkv [n_seq * T][3 * heads * 64] (q | k | v), out [n_seq * T][heads * 64].
+// part_o [kCfmAttnMaxSplit][n_seq * T][heads * 64] and part_ml [kCfmAttnMaxSplit][n_seq * T][heads][2] (both or neither):
+// scratch for the key split the launch uses when it has too few 16-query waves to fill the chip (merged in a second launch).
+constexpr int kCfmAttnMaxSplit = 8;
+hipError_t launch_cfm_attn(const float* qkv, float* out, int n_seq, int T, int heads, int head_dim, float* part_o, float* part_ml,
+                           hipStream_t s);
 // out[m] = mish(LayerNorm_C(in[m])) * mask[m] (+ add[m / T][0 .. C))     (causal_block1d, R/s3gen.R:186-196, :227)
 hipError_t launch_cfm_norm_mish(const float* in, const float* w, const float* b, const float* mask, const float* add, int add_ld,
                                 float* out, int M, int C, int T, float eps, hipStream_t s);
