@@ -1768,7 +1768,16 @@ hipError_t launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
     // 0.943 / 0.940 / 0.979; Turbo 16 x L 407..707 (256 blocks) 0.877 / 0.864 / 0.933; Turbo 8 (128) 0.823 / 0.840 / 0.919;
     // fp32 cache, 64 utterances 4.279 / 4.374 / 4.110.
     const long long blocks = (long long)a.M * a.n_heads;
-    const int nw = blocks >= 512 ? 1 : (blocks >= 256 ? 2 : 4);
+    static const int nw8_below = [] { const char* e = std::getenv("T3MI_ATTN_NW8"); return e ? std::atoi(e) : 0; }();   // experiment: 8 waves below this block count
+    const int nw = blocks >= 512 ? 1 : (blocks >= 256 ? 2 : (blocks < nw8_below ? 8 : 4));
+    if (nw == 8) {
+        const dim3 block(512);
+        if (a.kv_bf16 && a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, uint16_t, 8>), grid, block, 0, s, a);
+        else if (a.kv_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, float, 8>), grid, block, 0, s, a);
+        else if (a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<float, uint16_t, 8>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((attn_rows_kernel<float, float, 8>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     if (nw == 1) {
         const dim3 block(64);
         if (a.kv_bf16 && a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, uint16_t, 1>), grid, block, 0, s, a);

@@ -340,3 +340,95 @@ def synth_cfm_inputs(dims: CfmDims, T: int, seed: int, B: int = 1):
     cond[:, :, : T // 3] = rng.standard_normal((B, dims.mel, T // 3), dtype=F32)
     z = rng.standard_normal((B, dims.mel, T), dtype=F32)
     return mu, spks, cond, z
+
+
+# ---- S3Gen flow module: token embedding, speaker projection, conformer encoder, encoder projection --------
+
+@dataclass(frozen=True)
+class FlowDims:
+    """causal_masked_diff_xvec (R/s3gen.R:771-803) + upsample_conformer_encoder_full (R/conformer.R:467-510)."""
+    vocab: int = 6561
+    d: int = 512
+    heads: int = 8
+    ffn: int = 2048
+    n_blocks: int = 6
+    n_up: int = 4
+    spk: int = 192
+    cfm: CfmDims = CFM_FULL
+
+
+FLOW_FULL = FlowDims()
+FLOW_TINY = FlowDims(vocab=300, d=128, heads=2, ffn=256, n_blocks=2, n_up=1, spk=64, cfm=CFM_TINY)
+
+
+def synth_flow_weights(dims: FlowDims = FLOW_FULL, seed: int = 555) -> Dict[str, np.ndarray]:
+    """A synthetic s3gen checkpoint restricted to the flow module, keys as load_s3gen_weights / load_conformer_encoder_weights
+    read them (R/s3gen.R:1215-1231, R/conformer.R:627-713), the CFM estimator's tensors included."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    d, H, mel = dims.d, dims.heads, dims.cfm.mel
+    w: Dict[str, np.ndarray] = {}
+
+    def lin(name, o, i, bias=True, gain=0.7):
+        w[name + ".weight"] = (rng.standard_normal((o, i), dtype=F32) * F32(gain / np.sqrt(i))).astype(F32)
+        if bias:
+            w[name + ".bias"] = (rng.standard_normal(o, dtype=F32) * F32(0.05)).astype(F32)
+
+    def conv(name, o, i, k, gain=0.7):
+        w[name + ".weight"] = (rng.standard_normal((o, i, k), dtype=F32) * F32(gain / np.sqrt(i * k))).astype(F32)
+        w[name + ".bias"] = (rng.standard_normal(o, dtype=F32) * F32(0.05)).astype(F32)
+
+    def norm(name, n):
+        w[name + ".weight"] = (F32(1) + rng.standard_normal(n, dtype=F32) * F32(0.1)).astype(F32)
+        w[name + ".bias"] = (rng.standard_normal(n, dtype=F32) * F32(0.05)).astype(F32)
+
+    def layer(p):
+        for nm in ("linear_q", "linear_k", "linear_v"):
+            lin(p + "self_attn." + nm, d, d, gain=1.0)
+        lin(p + "self_attn.linear_out", d, d, gain=0.4)
+        lin(p + "self_attn.linear_pos", d, d, bias=False, gain=1.0)
+        w[p + "self_attn.pos_bias_u"] = (rng.standard_normal((H, d // H), dtype=F32) * F32(0.3)).astype(F32)
+        w[p + "self_attn.pos_bias_v"] = (rng.standard_normal((H, d // H), dtype=F32) * F32(0.3)).astype(F32)
+        lin(p + "feed_forward.w_1", dims.ffn, d)
+        lin(p + "feed_forward.w_2", d, dims.ffn, gain=0.4)
+        norm(p + "norm_mha", d)
+        norm(p + "norm_ff", d)
+
+    w["flow.input_embedding.weight"] = rng.standard_normal((dims.vocab, d), dtype=F32)
+    lin("flow.spk_embed_affine_layer", mel, dims.spk, gain=1.0)
+    lin("flow.encoder_proj", mel, d, gain=1.0)
+    e = "flow.encoder."
+    lin(e + "embed.out.0", d, d)
+    norm(e + "embed.out.1", d)
+    conv(e + "pre_lookahead_layer.conv1", d, d, 4)
+    conv(e + "pre_lookahead_layer.conv2", d, d, 3)
+    for i in range(dims.n_blocks):
+        layer(e + f"encoders.{i}.")
+    conv(e + "up_layer.conv", d, d, 5)
+    lin(e + "up_embed.out.0", d, d)
+    norm(e + "up_embed.out.1", d)
+    for i in range(dims.n_up):
+        layer(e + f"up_encoders.{i}.")
+    norm(e + "after_norm", d)
+    w.update(synth_cfm_weights(dims.cfm, seed + 222))
+    return w
+
+
+def ensure_flow_checkpoint(dims: FlowDims = FLOW_FULL, seed: int = 555, root: str | None = None) -> str:
+    root = root or os.environ.get("T3MI_SYNTH_DIR", "/tmp/t3mi_synth")
+    os.makedirs(root, exist_ok=True)
+    path = os.path.join(root, f"s3gen_flow_d{dims.d}_L{dims.n_blocks}+{dims.n_up}_V{dims.vocab}_C{dims.cfm.hidden}_s{seed}.safetensors")
+    if not os.path.exists(path):
+        write_safetensors(synth_flow_weights(dims, seed), path)
+    return path
+
+
+def synth_flow_inputs(dims: FlowDims, n_tokens: int, n_prompt: int, seed: int):
+    """speech tokens, prompt tokens, prompt mel [2 * n_prompt, mel], x-vector [spk], start noise (1, mel, 2 * (n_prompt + n_tokens))."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mel = dims.cfm.mel
+    tok = rng.integers(0, dims.vocab, n_tokens)
+    ptok = rng.integers(0, dims.vocab, n_prompt)
+    pfeat = rng.standard_normal((2 * n_prompt, mel), dtype=F32)
+    xvec = rng.standard_normal(dims.spk, dtype=F32)
+    z = rng.standard_normal((1, mel, 2 * (n_prompt + n_tokens)), dtype=F32)
+    return tok, ptok, pfeat, xvec, z

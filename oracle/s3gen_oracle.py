@@ -97,7 +97,8 @@ class CfmEstimatorOracle:
     def __init__(self, weights: Dict[str, np.ndarray], prefix: str = "flow.decoder.estimator.", heads: int = 8,
                  head_dim: int = 64, time_in: int = 320):
         self.w = {k[len(prefix):]: np.asarray(v, dtype=F32) for k, v in weights.items() if k.startswith(prefix)}
-        self.heads, self.head_dim, self.time_in = heads, head_dim, time_in
+        self.heads, self.head_dim = heads, head_dim
+        self.time_in = int(self.w["time_mlp.linear_1.weight"].shape[1]) if "time_mlp.linear_1.weight" in self.w else time_in
         self.n_mid = 0
         while f"mid_blocks.{self.n_mid}.0.block1.block.0.weight" in self.w:
             self.n_mid += 1
@@ -244,3 +245,160 @@ def basic_euler(est: CfmEstimatorOracle, z, mu, mask, spks, cond, n_timesteps: i
         d = est.forward(x, mask, mu, t, spks, cond, r=r)
         x = (x + F32(r[0] - t[0]) * d).astype(F32)
     return x
+
+
+# =====================================================================================================================
+# Conformer encoder (R/conformer.R:18-593) and the flow module around it (R/s3gen.R:768-891).  Same status as above:
+# pinned op-for-op against CPU libtorch (tests/test_s3gen_oracle_vs_torch.py), PARITY UNPINNED against the reference itself.
+# One utterance (B = 1), every position valid -- what s3gen$inference passes (R/s3gen.R:1006-1011): the padding masks of
+# R/conformer.R:259-267, 397-400 are then all-true and drop out.
+# =====================================================================================================================
+
+def conv1d_valid(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """nn_conv1d without padding on rows: x [T, Cin], w [Cout, Cin, k] -> [T - k + 1, Cout]."""
+    k = w.shape[2]
+    To = x.shape[0] - k + 1
+    y = np.zeros((To, w.shape[0]), F32)
+    for j in range(k):
+        y += (x[j:j + To].astype(F32) @ w[:, :, j].astype(F32).T).astype(F32)
+    return (y + b.astype(F32)).astype(F32)
+
+
+def rel_pos_emb(T: int, d_model: int) -> np.ndarray:
+    """espnet_rel_positional_encoding (R/conformer.R:34-95): the slice pe[center - T + 1 : center + T - 1] = rows for the
+    relative positions +(T - 1) ... 0 ... -(T - 1); even columns sin(pos * div), odd columns cos(pos * div), float32."""
+    div = np.exp(np.arange(0, d_model, 2, dtype=F32) * F32(-(math.log(10000.0) / d_model)), dtype=F32)
+    rel = np.arange(T - 1, -T, -1).astype(F32)                       # +(T-1) .. -(T-1)
+    ang = (rel[:, None] * div[None, :]).astype(F32)
+    pe = np.zeros((2 * T - 1, d_model), F32)
+    pe[:, 0::2] = np.sin(ang, dtype=F32)
+    pe[:, 1::2] = np.cos(ang, dtype=F32)
+    return pe
+
+
+def rel_shift(bd: np.ndarray) -> np.ndarray:
+    """rel_position_attention$rel_shift (R/conformer.R:281-307), literally: pad, view, drop the first row, view, crop.
+    bd [H, T, 2T - 1] -> [H, T, T]."""
+    H, T, P = bd.shape
+    x = np.concatenate([np.zeros((H, T, 1), F32), bd], axis=2)        # (H, T, P + 1)
+    x = x.reshape(H, P + 1, T)[:, 1:, :]                              # (H, P, T)
+    return x.reshape(H, T, P)[:, :, :T].copy()
+
+
+class ConformerOracle:
+    """upsample_conformer_encoder_full (R/conformer.R:464-593) over checkpoint tensors with `prefix` stripped."""
+
+    def __init__(self, weights: Dict[str, np.ndarray], prefix: str = "flow.encoder.", heads: int = 8):
+        self.w = {k[len(prefix):]: np.asarray(v, dtype=F32) for k, v in weights.items() if k.startswith(prefix)}
+        self.heads = heads
+        self.d = self.w["embed.out.0.weight"].shape[0]
+        self.n_blocks = 0
+        while f"encoders.{self.n_blocks}.norm_mha.weight" in self.w:
+            self.n_blocks += 1
+        self.n_up = 0
+        while f"up_encoders.{self.n_up}.norm_mha.weight" in self.w:
+            self.n_up += 1
+
+    def embed(self, x, p):
+        """linear_no_subsampling (R/conformer.R:124-134): Linear -> LayerNorm (eps 1e-5) -> * sqrt(d); pos_emb beside it."""
+        w = self.w
+        h = layer_norm(_lin(x, w[p + "out.0.weight"], w[p + "out.0.bias"]), w[p + "out.1.weight"], w[p + "out.1.bias"])
+        return (h * F32(math.sqrt(self.d))).astype(F32), rel_pos_emb(x.shape[0], self.d)
+
+    def pre_lookahead(self, x):
+        """pre_lookahead_layer (R/conformer.R:160-185): right-pad 3, conv k = 4, leaky_relu, left-pad 2, conv k = 3, + x."""
+        w = self.w
+        k1 = w["pre_lookahead_layer.conv1.weight"].shape[2]
+        h = np.concatenate([x, np.zeros((k1 - 1, x.shape[1]), F32)], axis=0)
+        h = conv1d_valid(h, w["pre_lookahead_layer.conv1.weight"], w["pre_lookahead_layer.conv1.bias"])
+        h = np.where(h >= 0, h, h * F32(0.01)).astype(F32)
+        h = np.concatenate([np.zeros((2, x.shape[1]), F32), h], axis=0)
+        h = conv1d_valid(h, w["pre_lookahead_layer.conv2.weight"], w["pre_lookahead_layer.conv2.bias"])
+        return (h + x).astype(F32)
+
+    def attention(self, x, pos_emb, p):
+        """rel_position_attention$forward (R/conformer.R:226-279), B = 1, no padding."""
+        w = self.w
+        T, H = x.shape[0], self.heads
+        dk = self.d // H
+        q = _lin(x, w[p + "linear_q.weight"], w[p + "linear_q.bias"]).reshape(T, H, dk).transpose(1, 0, 2)
+        k = _lin(x, w[p + "linear_k.weight"], w[p + "linear_k.bias"]).reshape(T, H, dk).transpose(1, 0, 2)
+        v = _lin(x, w[p + "linear_v.weight"], w[p + "linear_v.bias"]).reshape(T, H, dk).transpose(1, 0, 2)
+        pp = _lin(pos_emb, w[p + "linear_pos.weight"]).reshape(-1, H, dk).transpose(1, 0, 2)      # (H, 2T-1, dk)
+        qu = (q + w[p + "pos_bias_u"][:, None, :]).astype(F32)
+        qv = (q + w[p + "pos_bias_v"][:, None, :]).astype(F32)
+        ac = np.matmul(qu, k.transpose(0, 2, 1)).astype(F32)
+        bd = rel_shift(np.matmul(qv, pp.transpose(0, 2, 1)).astype(F32))
+        s = ((ac + bd) / F32(math.sqrt(dk))).astype(F32)
+        s = s - s.max(axis=-1, keepdims=True)
+        e = np.exp(s, dtype=F32)
+        a = (e / e.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
+        o = np.matmul(a, v).astype(F32).transpose(1, 0, 2).reshape(T, H * dk)
+        return _lin(o, w[p + "linear_out.weight"], w[p + "linear_out.bias"])
+
+    def layer(self, x, pos_emb, p):
+        """conformer_encoder_layer$forward (R/conformer.R:376-403): pre-norm attention and feed-forward, LayerNorm eps 1e-12."""
+        w = self.w
+        n = layer_norm(x, w[p + "norm_mha.weight"], w[p + "norm_mha.bias"], eps=1e-12)
+        x = (x + self.attention(n, pos_emb, p + "self_attn.")).astype(F32)
+        n = layer_norm(x, w[p + "norm_ff.weight"], w[p + "norm_ff.bias"], eps=1e-12)
+        f = _lin(silu(_lin(n, w[p + "feed_forward.w_1.weight"], w[p + "feed_forward.w_1.bias"])),
+                 w[p + "feed_forward.w_2.weight"], w[p + "feed_forward.w_2.bias"])
+        return (x + f).astype(F32)
+
+    def upsample(self, x):
+        """upsample_1d (R/conformer.R:426-444): nearest x 2, left-pad 4, conv k = 5."""
+        w = self.w
+        up = np.repeat(x, 2, axis=0)
+        k = w["up_layer.conv.weight"].shape[2]
+        up = np.concatenate([np.zeros((k - 1, x.shape[1]), F32), up], axis=0)
+        return conv1d_valid(up, w["up_layer.conv.weight"], w["up_layer.conv.bias"])
+
+    def forward(self, x: np.ndarray) -> np.ndarray:
+        """x [T, d] (embedded tokens) -> [2T, d]  (R/conformer.R:517-578)."""
+        w = self.w
+        xs, pe = self.embed(x.astype(F32), "embed.")
+        xs = self.pre_lookahead(xs)
+        for i in range(self.n_blocks):
+            xs = self.layer(xs, pe, f"encoders.{i}.")
+        xs = self.upsample(xs)
+        xs, pe = self.embed(xs, "up_embed.")
+        for i in range(self.n_up):
+            xs = self.layer(xs, pe, f"up_encoders.{i}.")
+        return layer_norm(xs, w["after_norm.weight"], w["after_norm.bias"])
+
+
+def flow_inputs(weights: Dict[str, np.ndarray], token, prompt_token, prompt_feat, embedding, heads: int = 8,
+                finalize: bool = True, vocab_size: int = 6561):
+    """causal_masked_diff_xvec$forward up to the decoder call (R/s3gen.R:805-872), B = 1: returns (mu (1, 80, T), spks (1, 80),
+    cond (1, 80, T), mel_len1).  token / prompt_token: 0-indexed ids; prompt_feat [frames, 80]; embedding [192]."""
+    w = weights
+    emb = np.asarray(embedding, dtype=F32).reshape(-1)
+    emb = (emb / np.maximum(np.sqrt((emb * emb).sum(dtype=F32), dtype=F32), F32(1e-12))).astype(F32)      # nnf_normalize, :822
+    spks = _lin(emb[None, :], w["flow.spk_embed_affine_layer.weight"], w["flow.spk_embed_affine_layer.bias"])   # :823
+    tok = np.concatenate([np.asarray(prompt_token, np.int64).reshape(-1), np.asarray(token, np.int64).reshape(-1)])   # :826
+    tok = np.clip(tok, 0, vocab_size - 1)                                                                   # :833
+    x = w["flow.input_embedding.weight"][tok].astype(F32)                                                    # :836 (mask all ones)
+    h = ConformerOracle(w, "flow.encoder.", heads).forward(x)                                               # :839
+    if not finalize:
+        h = h[: h.shape[0] - 3 * 2]                                                                         # :844-846
+    mel_len1 = 2 * int(np.asarray(prompt_token).size)
+    mel_len2 = h.shape[0] - mel_len1
+    h = _lin(h, w["flow.encoder_proj.weight"], w["flow.encoder_proj.bias"])                                  # :854
+    pf = np.asarray(prompt_feat, dtype=F32)
+    conds = np.zeros((mel_len1 + mel_len2, h.shape[1]), F32)                                                # :857-865
+    n = min(pf.shape[0], mel_len1)
+    conds[:n] = pf[:n]
+    return h.T[None].copy(), spks, conds.T[None].copy(), mel_len1
+
+
+def flow_inference(weights, token, prompt_token, prompt_feat, embedding, noise, n_timesteps: int = 10, heads: int = 8,
+                   cfm_heads: int = 8, finalize: bool = True, meanflow: bool = False) -> np.ndarray:
+    """causal_masked_diff_xvec$forward (R/s3gen.R:805-890): tokens -> mel of the generated part (1, 80, mel_len2)."""
+    mu, spks, cond, mel_len1 = flow_inputs(weights, token, prompt_token, prompt_feat, embedding, heads, finalize)
+    T = mu.shape[2]
+    mask = np.ones((1, 1, T), F32)
+    est = CfmEstimatorOracle(weights, heads=cfm_heads)
+    z = np.asarray(noise, dtype=F32)[:, :, :T]
+    feat = basic_euler(est, z, mu, mask, spks, cond, n_timesteps) if meanflow else solve_euler(est, z, mu, mask, spks, cond, n_timesteps)
+    return feat[:, :, mel_len1:].copy()                                                                      # :887

@@ -158,3 +158,109 @@ def test_synthetic_checkpoint_has_the_loader_layout():
     assert w[p + "final_proj.weight"].shape == (80, 256, 1)
     n_tfm = sum(1 for k in w if k.endswith("norm1.weight"))
     assert n_tfm == 56 and sum(v.size for v in w.values()) > 60e6
+
+
+# ---- conformer encoder + flow module (R/conformer.R, R/s3gen.R:805-890) ------------------------------------------------
+
+class TorchConformer:
+    """upsample_conformer_encoder_full$forward written with the ATen calls of R/conformer.R, B = 1, no padding."""
+
+    def __init__(self, w, dims, prefix="flow.encoder."):
+        self.w = {k[len(prefix):]: torch.from_numpy(v) for k, v in w.items() if k.startswith(prefix)}
+        self.d, self.H = dims.d, dims.heads
+
+    def pe(self, T, max_len=700):
+        d = self.d
+        position = torch.arange(0, max_len, dtype=torch.float32).unsqueeze(1)
+        div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * (-(np.log(10000.0) / d)))
+        pos = torch.zeros(max_len, d); neg = torch.zeros(max_len, d)
+        pos[:, 0::2] = torch.sin(position * div); pos[:, 1::2] = torch.cos(position * div)
+        neg[:, 0::2] = torch.sin(-1 * position * div); neg[:, 1::2] = torch.cos(-1 * position * div)
+        pe = torch.cat([torch.flip(pos, [0]), neg[1:]], dim=0).unsqueeze(0)       # R/conformer.R:58-69
+        center = max_len                                                           # 1-indexed centre (:83)
+        return pe[:, center - T:center + T - 1]                                    # rows start_idx..end_idx, 1-indexed inclusive
+
+    def embed(self, x, p):
+        w = self.w
+        h = F.layer_norm(F.linear(x, w[p + "out.0.weight"], w[p + "out.0.bias"]), (self.d,), w[p + "out.1.weight"], w[p + "out.1.bias"])
+        return h * np.sqrt(self.d), self.pe(x.shape[1])
+
+    def rel_shift(self, x):
+        b, h, t, p = x.shape
+        x = F.pad(x, (1, 0)).view(b, h, p + 1, t)[:, :, 1:, :]
+        return x.reshape(b, h, t, p)[:, :, :, :t].contiguous()
+
+    def attn(self, x, pos, p):
+        w, H = self.w, self.H
+        B, T, d = x.shape
+        dk = d // H
+        q, k, v = (F.linear(x, w[p + f"linear_{c}.weight"], w[p + f"linear_{c}.bias"]).view(B, -1, H, dk).transpose(1, 2) for c in "qkv")
+        pp = F.linear(pos, w[p + "linear_pos.weight"]).view(1, -1, H, dk).transpose(1, 2)
+        qu = q + w[p + "pos_bias_u"].unsqueeze(0).unsqueeze(2)
+        qv = q + w[p + "pos_bias_v"].unsqueeze(0).unsqueeze(2)
+        s = (torch.matmul(qu, k.transpose(-2, -1)) + self.rel_shift(torch.matmul(qv, pp.transpose(-2, -1)))) / np.sqrt(dk)
+        o = torch.matmul(torch.softmax(s, dim=-1), v).transpose(1, 2).contiguous().view(B, -1, d)
+        return F.linear(o, w[p + "linear_out.weight"], w[p + "linear_out.bias"])
+
+    def layer(self, x, pos, p):
+        w = self.w
+        n = F.layer_norm(x, (self.d,), w[p + "norm_mha.weight"], w[p + "norm_mha.bias"], eps=1e-12)
+        x = x + self.attn(n, pos, p + "self_attn.")
+        n = F.layer_norm(x, (self.d,), w[p + "norm_ff.weight"], w[p + "norm_ff.bias"], eps=1e-12)
+        return x + F.linear(F.silu(F.linear(n, w[p + "feed_forward.w_1.weight"], w[p + "feed_forward.w_1.bias"])),
+                            w[p + "feed_forward.w_2.weight"], w[p + "feed_forward.w_2.bias"])
+
+    def forward(self, x, n_blocks, n_up):
+        w = self.w
+        xs, pos = self.embed(x, "embed.")
+        h = F.pad(xs.transpose(1, 2), (0, 3))
+        h = F.leaky_relu(F.conv1d(h, w["pre_lookahead_layer.conv1.weight"], w["pre_lookahead_layer.conv1.bias"]))
+        h = F.conv1d(F.pad(h, (2, 0)), w["pre_lookahead_layer.conv2.weight"], w["pre_lookahead_layer.conv2.bias"])
+        xs = h.transpose(1, 2) + xs
+        for i in range(n_blocks):
+            xs = self.layer(xs, pos, f"encoders.{i}.")
+        h = F.interpolate(xs.transpose(1, 2), scale_factor=2.0, mode="nearest")
+        h = F.conv1d(F.pad(h, (4, 0)), w["up_layer.conv.weight"], w["up_layer.conv.bias"])
+        xs, pos = self.embed(h.transpose(1, 2), "up_embed.")
+        for i in range(n_up):
+            xs = self.layer(xs, pos, f"up_encoders.{i}.")
+        return F.layer_norm(xs, (self.d,), w["after_norm.weight"], w["after_norm.bias"])
+
+
+@pytest.mark.parametrize("dims,T", [(synth.FLOW_TINY, 23), (synth.FlowDims(n_blocks=1, n_up=1, cfm=synth.CFM_TINY), 31)], ids=["tiny", "full-width"])
+def test_conformer_encoder_matches_libtorch(dims, T):
+    w = synth.synth_flow_weights(dims, 555)
+    x = np.random.default_rng(2).standard_normal((T, dims.d)).astype(np.float32)
+    got = S.ConformerOracle(w, heads=dims.heads).forward(x)
+    with torch.no_grad():
+        want = TorchConformer(w, dims).forward(torch.from_numpy(x)[None], dims.n_blocks, dims.n_up)[0].numpy()
+    assert got.shape == (2 * T, dims.d)
+    assert np.abs(got - want).max() < 3e-5 * max(1.0, np.abs(want).max())
+
+
+def test_rel_shift_picks_the_relative_position():
+    """After rel_shift entry (i, j) is column T - 1 - i + j of the raw product: the row of relative position i - j."""
+    T = 7
+    bd = np.arange(2 * T * (2 * T - 1), dtype=np.float32).reshape(2, T, 2 * T - 1)
+    sh = S.rel_shift(bd)
+    for i in range(T):
+        for j in range(T):
+            assert sh[1, i, j] == bd[1, i, T - 1 - i + j]
+
+
+def test_flow_inputs_and_inference_shapes():
+    """causal_masked_diff_xvec$forward (R/s3gen.R:805-890) on the tiny model: mel_len1 = 2 x prompt tokens, the conditioning
+    holds the prompt mel over those frames and zeros after, the result is the generated part only."""
+    dims = synth.FLOW_TINY
+    w = synth.synth_flow_weights(dims, 555)
+    tok, ptok, pfeat, xvec, z = synth.synth_flow_inputs(dims, 9, 6, 4)
+    mu, spks, cond, l1 = S.flow_inputs(w, tok, ptok, pfeat, xvec, heads=dims.heads)
+    assert l1 == 12 and mu.shape == (1, dims.cfm.mel, 30) and spks.shape == (1, dims.cfm.mel)
+    assert np.array_equal(cond[0, :, :12], pfeat.T) and not cond[0, :, 12:].any()
+    with torch.no_grad():
+        e = torch.from_numpy(xvec)[None]
+        want = F.linear(F.normalize(e, dim=1), torch.from_numpy(w["flow.spk_embed_affine_layer.weight"]),
+                        torch.from_numpy(w["flow.spk_embed_affine_layer.bias"])).numpy()
+    assert np.abs(spks - want).max() < 1e-6
+    out = S.flow_inference(w, tok, ptok, pfeat, xvec, z, n_timesteps=3, heads=dims.heads, cfm_heads=dims.cfm.heads)
+    assert out.shape == (1, dims.cfm.mel, 18) and np.isfinite(out).all()
