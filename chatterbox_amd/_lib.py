@@ -58,6 +58,11 @@ class CfmInfo(C.Structure):
                                          "meanflow", "device", "reserved_")] + [("weight_bytes", C.c_int64)]
 
 
+class FlowInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab", "d_model", "heads", "d_ff", "n_blocks", "n_up_blocks", "spk_embed_dim", "mel")] + \
+               [("weight_bytes", C.c_int64)]
+
+
 class KStat(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_int32), ("total_us", C.c_float),
                 ("bytes", C.c_double)]
@@ -107,6 +112,11 @@ SYMBOLS = {
     "t3mi_cfm_close": (C.c_int, [_H]),
     "t3mi_cfm_get_info": (C.c_int, [_H, C.POINTER(CfmInfo)]),
     "t3mi_cfm_estimator": (C.c_int, [_H, C.c_int, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
+    "t3mi_flow_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_H)]),
+    "t3mi_flow_get_info": (C.c_int, [_H, C.POINTER(FlowInfo)]),
+    "t3mi_flow_encoder": (C.c_int, [_H, C.c_int, _FP, _FP]),
+    "t3mi_flow_inference": (C.c_int, [_H, _IP, C.c_int, _IP, C.c_int, _FP, C.c_int, _FP, _FP, C.c_int, C.c_int, C.c_double, C.c_int,
+                                      C.c_int, _FP, C.c_int, C.POINTER(C.c_int), _FP]),
     "t3mi_cfm_solve": (C.c_int, [_H, C.c_int, _FP, _FP, _FP, _FP, _FP, C.c_int, C.c_double, C.c_int, _FP, _FP]),
 }
 

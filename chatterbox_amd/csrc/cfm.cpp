@@ -70,6 +70,23 @@ struct Tfm {
     Lin qkv, out, ff1, ff2;
 };
 
+struct ConfLayer {    // conformer_encoder_layer (R/conformer.R:356-404)
+    Norm n_mha, n_ff;
+    Lin qkv, pos, out, w1, w2;          // qkv: linear_q | linear_k | linear_v stacked (weights and biases)
+    const float *bias_u = nullptr, *bias_v = nullptr;   // pos_bias_u / pos_bias_v [heads][64]
+};
+struct Flow {         // causal_masked_diff_xvec (R/s3gen.R:771-803) without its decoder
+    int vocab = 0, d = 0, heads = 0, ffn = 0, spk = 0, n_blocks = 0, n_up = 0;
+    const float* embedding = nullptr;   // input_embedding [vocab][d]
+    Lin spk_affine, enc_proj, embed, up_embed, pre1, pre2, up_conv;
+    Norm embed_n, up_embed_n, after_norm;
+    int pre1_k = 4, up_k = 5;
+    std::vector<ConfLayer> layers;      // encoders then up_encoders
+    Buf wbuf;
+    Buf ids, x0, xs, xn, col, qkv, ao, ffb, pe, pp, bd, apo, apml, part, mu, spk_in, spk_out;
+    size_t ws_T = 0;
+};
+
 }  // namespace
 
 struct t3mi_cfm {
@@ -89,6 +106,7 @@ struct t3mi_cfm {
     Buf gpart;          // K-split partial slabs of the GEMMs with few feature tiles (launch_gemm's `part`)
     size_t ws_rows = 0;
     int ws_B = 0;
+    std::unique_ptr<Flow> flow;        // t3mi_flow_open: the modules in front of the estimator
 };
 
 namespace {
@@ -410,6 +428,197 @@ void to_rows(const float* src, int B, int C, int T, float* dst, int ld, int col0
         }
 }
 
+// ---- flow module: checkpoint -> HBM (keys of load_s3gen_weights R/s3gen.R:1215-1228, load_conformer_encoder_weights
+// R/conformer.R:627-713) ------------------------------------------------------------------------------------------
+int load_flow(t3mi_cfm* m, const t3mi::SafeTensorsFile& st) {
+    std::unique_ptr<Flow> f(new Flow());
+    const t3mi::StTensor* emb = st.find("flow.input_embedding.weight");
+    const t3mi::StTensor* sa = st.find("flow.spk_embed_affine_layer.weight");
+    const t3mi::StTensor* w1 = st.find("flow.encoder.encoders.0.feed_forward.w_1.weight");
+    const t3mi::StTensor* c1 = st.find("flow.encoder.pre_lookahead_layer.conv1.weight");
+    const t3mi::StTensor* uc = st.find("flow.encoder.up_layer.conv.weight");
+    const t3mi::StTensor* bu = st.find("flow.encoder.encoders.0.self_attn.pos_bias_u");
+    if (!emb || !sa || !w1 || !c1 || !uc || !bu || emb->shape.size() != 2 || sa->shape.size() != 2 || w1->shape.size() != 2 ||
+        c1->shape.size() != 3 || uc->shape.size() != 3 || bu->shape.size() != 2)
+        return fail(T3MI_ERR_IO, "checkpoint lacks the S3Gen flow tensors (flow.input_embedding, flow.spk_embed_affine_layer, flow.encoder.*)");
+    for (const t3mi::StTensor* t : {emb, sa, w1, c1, uc, bu})
+        for (int64_t sdim : t->shape)
+            if (sdim <= 0 || sdim > (1 << 24)) return fail(T3MI_ERR_IO, "flow checkpoint: implausible tensor extents");
+    f->vocab = (int)emb->shape[0];
+    f->d = (int)emb->shape[1];
+    f->spk = (int)sa->shape[1];
+    f->ffn = (int)w1->shape[0];
+    f->heads = (int)bu->shape[0];
+    f->pre1_k = (int)c1->shape[2];
+    f->up_k = (int)uc->shape[2];
+    const int d = f->d;
+    if ((int)sa->shape[0] != m->mel) return fail(T3MI_ERR_IO, "flow.spk_embed_affine_layer does not project to the estimator's mel bins");
+    if (f->heads <= 0 || d != f->heads * 64 || (int)bu->shape[1] != 64)
+        return fail(T3MI_ERR_IO, "conformer encoder: attention needs heads x 64 = model dimension (R/conformer.R:203-208)");
+    if (d % 64 || f->ffn % 64 || f->spk % 64 || f->pre1_k < 1 || f->pre1_k > 8 || f->up_k < 1 || f->up_k > 8)
+        return fail(T3MI_ERR_IO, "conformer encoder: dimensions must be multiples of 64 and kernels at most 8 taps");
+    while (st.find("flow.encoder.encoders." + std::to_string(f->n_blocks) + ".norm_mha.weight")) ++f->n_blocks;
+    while (st.find("flow.encoder.up_encoders." + std::to_string(f->n_up) + ".norm_mha.weight")) ++f->n_up;
+
+    Loader L{m, st, "flow.", {}, ""};
+    std::vector<Pending> pend;
+    bool ok = true;
+    auto reg = [&](const float** slot, long long off) {
+        if (off < 0) ok = false;
+        pend.push_back({slot, off});
+    };
+    auto lin = [&](Lin& l, const std::string& key, int N, int K, bool bias) {
+        l.N = N; l.K = K;
+        if (ok) reg(&l.w, L.put(key + ".weight", {N, K}));
+        if (bias && ok) reg(&l.b, L.put(key + ".bias", {N}));
+    };
+    auto conv = [&](Lin& l, const std::string& key, int O, int I, int k) {
+        l.N = O; l.K = I * k;
+        if (ok) reg(&l.w, L.put_conv(key + ".weight", O, I, k));
+        if (ok) reg(&l.b, L.put(key + ".bias", {O}));
+    };
+    auto norm = [&](Norm& n, const std::string& key, int dd) {
+        if (ok) reg(&n.w, L.put(key + ".weight", {dd}));
+        if (ok) reg(&n.b, L.put(key + ".bias", {dd}));
+    };
+    reg(&f->embedding, L.put("input_embedding.weight", {f->vocab, d}));
+    lin(f->spk_affine, "spk_embed_affine_layer", m->mel, f->spk, true);
+    lin(f->enc_proj, "encoder_proj", m->mel, d, true);
+    lin(f->embed, "encoder.embed.out.0", d, d, true);
+    norm(f->embed_n, "encoder.embed.out.1", d);
+    conv(f->pre1, "encoder.pre_lookahead_layer.conv1", d, d, f->pre1_k);
+    conv(f->pre2, "encoder.pre_lookahead_layer.conv2", d, d, 3);
+    conv(f->up_conv, "encoder.up_layer.conv", d, d, f->up_k);
+    lin(f->up_embed, "encoder.up_embed.out.0", d, d, true);
+    norm(f->up_embed_n, "encoder.up_embed.out.1", d);
+    norm(f->after_norm, "encoder.after_norm", d);
+    f->layers.resize((size_t)f->n_blocks + f->n_up);
+    for (int i = 0; i < f->n_blocks + f->n_up && ok; ++i) {
+        ConfLayer& l = f->layers[i];
+        const std::string p = i < f->n_blocks ? "encoder.encoders." + std::to_string(i) + "."
+                                              : "encoder.up_encoders." + std::to_string(i - f->n_blocks) + ".";
+        norm(l.n_mha, p + "norm_mha", d);
+        norm(l.n_ff, p + "norm_ff", d);
+        l.qkv.N = 3 * d; l.qkv.K = d;
+        const long long wq = ok ? L.put(p + "self_attn.linear_q.weight", {d, d}) : -1;
+        const long long wk = wq >= 0 ? L.put(p + "self_attn.linear_k.weight", {d, d}) : -1;
+        const long long wv = wk >= 0 ? L.put(p + "self_attn.linear_v.weight", {d, d}) : -1;
+        const long long bq = wv >= 0 ? L.put(p + "self_attn.linear_q.bias", {d}) : -1;
+        const long long bk = bq >= 0 ? L.put(p + "self_attn.linear_k.bias", {d}) : -1;
+        const long long bvv = bk >= 0 ? L.put(p + "self_attn.linear_v.bias", {d}) : -1;
+        if (bvv < 0) { ok = false; break; }
+        reg(&l.qkv.w, wq);
+        reg(&l.qkv.b, bq);
+        lin(l.pos, p + "self_attn.linear_pos", d, d, false);
+        lin(l.out, p + "self_attn.linear_out", d, d, true);
+        if (ok) reg(&l.bias_u, L.put(p + "self_attn.pos_bias_u", {f->heads, 64}));
+        if (ok) reg(&l.bias_v, L.put(p + "self_attn.pos_bias_v", {f->heads, 64}));
+        lin(l.w1, p + "feed_forward.w_1", f->ffn, d, true);
+        lin(l.w2, p + "feed_forward.w_2", d, f->ffn, true);
+    }
+    if (!ok) return fail(T3MI_ERR_IO, L.err.empty() ? "flow checkpoint: malformed tensor" : L.err);
+    HIPCHK(f->wbuf.need(L.host.size() * 4));
+    HIPCHK(hipMemcpy(f->wbuf.p, L.host.data(), L.host.size() * 4, hipMemcpyHostToDevice));
+    for (const Pending& p : pend) *p.slot = f->wbuf.f() + p.off;
+    m->weight_bytes += (int64_t)L.host.size() * 4;
+    m->flow = std::move(f);
+    return T3MI_OK;
+}
+
+int flow_ws(t3mi_cfm* m, int T) {   // T = tokens; the up stage runs at 2T
+    Flow* f = m->flow.get();
+    if ((size_t)T <= f->ws_T) return T3MI_OK;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    const size_t T2 = 2 * (size_t)T, d = f->d, kmax = std::max(std::max(f->pre1_k, f->up_k), 3);
+    HIPCHK(f->ids.need(T2 * 4));
+    HIPCHK(f->x0.need(T2 * d * 4));
+    HIPCHK(f->xs.need(T2 * d * 4));
+    HIPCHK(f->xn.need(T2 * d * 4));
+    HIPCHK(f->col.need(T2 * kmax * d * 4));
+    HIPCHK(f->qkv.need(T2 * 3 * d * 4));
+    HIPCHK(f->ao.need(T2 * d * 4));
+    HIPCHK(f->ffb.need(T2 * f->ffn * 4));
+    HIPCHK(f->pe.need(2 * T2 * d * 4));
+    HIPCHK(f->pp.need(2 * T2 * d * 4));
+    HIPCHK(f->bd.need((size_t)f->heads * T2 * 2 * T2 * 4));
+    HIPCHK(f->apo.need((size_t)t3k::kCfmAttnMaxSplit * T2 * d * 4));
+    HIPCHK(f->apml.need((size_t)t3k::kCfmAttnMaxSplit * T2 * f->heads * 2 * 4));
+    HIPCHK(f->part.need((size_t)16 * T2 * d * 4));
+    HIPCHK(f->mu.need(T2 * m->mel * 4));
+    HIPCHK(f->spk_in.need((size_t)f->spk * 4));
+    HIPCHK(f->spk_out.need((size_t)m->mel * 4));
+    f->ws_T = (size_t)T;
+    return T3MI_OK;
+}
+
+int fgemm(t3mi_cfm* m, const float* A, const Lin& l, int M, int epi, float* y, const float* resid) {
+    Flow* f = m->flow.get();
+    t3k::GemmArgs a;
+    a.W = l.w; a.A = A; a.M = M; a.N = l.N; a.K = l.K; a.bias = l.b;
+    a.y = y; a.resid = resid; a.ldy = l.N;
+    if (l.N <= f->d && M >= 64) {   // few feature tiles: K split over blocks, folded in a fixed order
+        a.part = f->part.f();
+        a.part_floats = f->part.bytes / 4;
+    }
+    HIPCHK(t3k::launch_gemm(a, epi, 0, m->stream));
+    return T3MI_OK;
+}
+
+// linear_no_subsampling (R/conformer.R:124-134): Linear -> LayerNorm -> * sqrt(d) into xs; pos_emb for T rows into pe
+int conf_embed(t3mi_cfm* m, const float* x, const Lin& l, const Norm& n, int T) {
+    Flow* f = m->flow.get();
+    int rc = fgemm(m, x, l, T, t3k::EPI_STORE, f->xn.f(), nullptr);
+    if (rc) return rc;
+    HIPCHK(t3k::launch_layernorm_rows(f->xn.f(), n.w, n.b, 1e-5f, f->xs.p, T, f->d, 0, m->stream));
+    HIPCHK(t3k::launch_cfm_act(f->xs.f(), f->xs.f(), (size_t)T * f->d, 3, m->stream, sqrtf((float)f->d)));
+    HIPCHK(t3k::launch_rel_pos_emb(f->pe.f(), T, f->d, m->stream));
+    return T3MI_OK;
+}
+
+// conformer_encoder_layer$forward (R/conformer.R:376-403) in place on xs [T][d]; pe holds the 2T - 1 position rows
+int conf_layer(t3mi_cfm* m, const ConfLayer& l, int T) {
+    Flow* f = m->flow.get();
+    const int d = f->d;
+    float* x = f->xs.f();
+    HIPCHK(t3k::launch_layernorm_rows(x, l.n_mha.w, l.n_mha.b, 1e-12f, f->xn.p, T, d, 0, m->stream));
+    int rc = fgemm(m, f->xn.f(), l.qkv, T, t3k::EPI_STORE, f->qkv.f(), nullptr);
+    if (rc) return rc;
+    if ((rc = fgemm(m, f->pe.f(), l.pos, 2 * T - 1, t3k::EPI_STORE, f->pp.f(), nullptr))) return rc;     // linear_pos(pos_emb), :241
+    HIPCHK(t3k::launch_conf_bd(f->qkv.f(), 3 * d, l.bias_v, f->pp.f(), d, f->bd.f(), T, f->heads, m->stream));
+    HIPCHK(t3k::launch_cfm_attn(f->qkv.f(), f->ao.f(), 1, T, f->heads, 64, f->apo.f(), f->apml.f(), m->stream, l.bias_u, f->bd.f()));
+    if ((rc = fgemm(m, f->ao.f(), l.out, T, t3k::EPI_RESID, x, x))) return rc;
+    HIPCHK(t3k::launch_layernorm_rows(x, l.n_ff.w, l.n_ff.b, 1e-12f, f->xn.p, T, d, 0, m->stream));
+    if ((rc = fgemm(m, f->xn.f(), l.w1, T, t3k::EPI_STORE, f->ffb.f(), nullptr))) return rc;
+    HIPCHK(t3k::launch_cfm_act(f->ffb.f(), f->ffb.f(), (size_t)T * f->ffn, 0, m->stream));
+    return fgemm(m, f->ffb.f(), l.w2, T, t3k::EPI_RESID, x, x);
+}
+
+// upsample_conformer_encoder_full$forward (R/conformer.R:517-578), one sequence, every position valid:
+// x0 [T][d] (embedded tokens) -> xs [2T][d]
+int encoder_rows(t3mi_cfm* m, int T) {
+    Flow* f = m->flow.get();
+    const int d = f->d;
+    int rc = conf_embed(m, f->x0.f(), f->embed, f->embed_n, T);
+    if (rc) return rc;
+    // pre_lookahead_layer (:160-185): look-ahead conv -> leaky_relu -> causal conv -> + residual
+    HIPCHK(t3k::launch_rows_window(f->xs.f(), f->col.f(), T, T, d, f->pre1_k, 0, 1, m->stream));
+    if ((rc = fgemm(m, f->col.f(), f->pre1, T, t3k::EPI_STORE, f->xn.f(), nullptr))) return rc;
+    HIPCHK(t3k::launch_cfm_act(f->xn.f(), f->xn.f(), (size_t)T * d, 2, m->stream));
+    HIPCHK(t3k::launch_rows_window(f->xn.f(), f->col.f(), T, T, d, 3, -2, 1, m->stream));
+    if ((rc = fgemm(m, f->col.f(), f->pre2, T, t3k::EPI_RESID, f->xs.f(), f->xs.f()))) return rc;
+    for (int i = 0; i < f->n_blocks; ++i)
+        if ((rc = conf_layer(m, f->layers[i], T))) return rc;
+    // upsample_1d (:426-444): nearest x 2, left pad, conv
+    const int T2 = 2 * T;
+    HIPCHK(t3k::launch_rows_window(f->xs.f(), f->col.f(), T2, T, d, f->up_k, -(f->up_k - 1), 2, m->stream));
+    if ((rc = fgemm(m, f->col.f(), f->up_conv, T2, t3k::EPI_STORE, f->x0.f(), nullptr))) return rc;
+    if ((rc = conf_embed(m, f->x0.f(), f->up_embed, f->up_embed_n, T2))) return rc;
+    for (int i = 0; i < f->n_up; ++i)
+        if ((rc = conf_layer(m, f->layers[(size_t)f->n_blocks + i], T2))) return rc;
+    HIPCHK(t3k::launch_layernorm_rows(f->xs.f(), f->after_norm.w, f->after_norm.b, 1e-5f, f->xn.p, T2, d, 0, m->stream));
+    return T3MI_OK;   // result in xn [2T][d]
+}
+
 int check_handle(t3mi_cfm* m) {
     if (!m) return fail(T3MI_ERR_ARG, "null CFM handle");
     return T3MI_OK;
@@ -573,6 +782,128 @@ int t3mi_cfm_solve(t3mi_cfm* m, int T, const float* z, const float* mu, const fl
     HIPCHK(hipStreamSynchronize(st));
     for (int c = 0; c < mel; ++c)
         for (int tq = 0; tq < T; ++tq) out[(size_t)c * T + tq] = xr[(size_t)tq * mel + c];
+    return T3MI_OK;
+}
+
+int t3mi_flow_open(const char* path, int device, t3mi_cfm** out) {
+    if (!path || !out) return fail(T3MI_ERR_ARG, "t3mi_flow_open: null argument");
+    *out = nullptr;
+    t3mi_cfm* m = nullptr;
+    int rc = t3mi_cfm_open(path, "flow.decoder.estimator.", device, 0, &m);
+    if (rc) return rc;
+    t3mi::SafeTensorsFile st;
+    std::string err;
+    if (!st.open(path, err)) { t3mi_cfm_close(m); return fail(T3MI_ERR_IO, err); }
+    if ((rc = load_flow(m, st))) {
+        const std::string keep = t3mi_last_error();
+        t3mi_cfm_close(m);
+        return fail(rc, keep);
+    }
+    *out = m;
+    return T3MI_OK;
+}
+
+int t3mi_flow_get_info(const t3mi_cfm* m, t3mi_flow_info* info) {
+    if (!m || !info) return fail(T3MI_ERR_ARG, "t3mi_flow_get_info: null argument");
+    if (!m->flow) return fail(T3MI_ERR_STATE, "not a flow handle (open it with t3mi_flow_open)");
+    const Flow* f = m->flow.get();
+    info->vocab = f->vocab; info->d_model = f->d; info->heads = f->heads; info->d_ff = f->ffn; info->n_blocks = f->n_blocks;
+    info->n_up_blocks = f->n_up; info->spk_embed_dim = f->spk; info->mel = m->mel;
+    info->weight_bytes = m->weight_bytes;
+    return T3MI_OK;
+}
+
+int t3mi_flow_encoder(t3mi_cfm* m, int T, const float* x, float* out) {
+    int rc = check_handle(m);
+    if (rc) return rc;
+    if (!m->flow) return fail(T3MI_ERR_STATE, "not a flow handle (open it with t3mi_flow_open)");
+    if (!x || !out || T <= 0 || T > (1 << 16)) return fail(T3MI_ERR_ARG, "t3mi_flow_encoder: bad argument");
+    HIPCHK(hipSetDevice(m->device));
+    if ((rc = flow_ws(m, T))) return rc;
+    Flow* f = m->flow.get();
+    HIPCHK(hipMemcpyAsync(f->x0.p, x, (size_t)T * f->d * 4, hipMemcpyHostToDevice, m->stream));
+    if ((rc = encoder_rows(m, T))) return rc;
+    HIPCHK(hipMemcpyAsync(out, f->xn.p, (size_t)2 * T * f->d * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return T3MI_OK;
+}
+
+int t3mi_flow_inference(t3mi_cfm* m, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt,
+                        const float* prompt_feat, int n_feat, const float* embedding, const float* noise, int noise_T,
+                        int n_timesteps, double cfg_rate, int meanflow, int finalize, float* out, int cap_frames, int* n_frames,
+                        float* device_ms) {
+    int rc = check_handle(m);
+    if (rc) return rc;
+    if (!m->flow) return fail(T3MI_ERR_STATE, "not a flow handle (open it with t3mi_flow_open)");
+    if (!token || !prompt_token || !prompt_feat || !embedding || !noise || !out || !n_frames)
+        return fail(T3MI_ERR_ARG, "t3mi_flow_inference: null argument");
+    if (n_token <= 0 || n_prompt < 0 || n_feat < 0 || n_token + n_prompt > (1 << 16)) return fail(T3MI_ERR_ARG, "t3mi_flow_inference: bad token counts");
+    HIPCHK(hipSetDevice(m->device));
+    Flow* f = m->flow.get();
+    const int T = n_prompt + n_token, mel = m->mel;
+    if ((rc = flow_ws(m, T))) return rc;
+    hipStream_t st = m->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (device_ms) {
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, st));
+    }
+    // token <- cat(prompt_token, token), clamped to the table (R/s3gen.R:826-836; the mask is all ones for one utterance)
+    std::vector<int32_t> ids((size_t)T);
+    for (int i = 0; i < T; ++i) {
+        const int32_t v = i < n_prompt ? prompt_token[i] : token[i - n_prompt];
+        ids[i] = std::min(std::max(v, 0), f->vocab - 1);
+    }
+    // embedding <- spk_embed_affine_layer(nnf_normalize(embedding)) (R/s3gen.R:822-823): the 192-float norm on the host
+    std::vector<float> en((size_t)f->spk);
+    {
+        float ss = 0.f;
+        for (int i = 0; i < f->spk; ++i) ss += embedding[i] * embedding[i];
+        const float nrm = std::max(sqrtf(ss), 1e-12f);
+        for (int i = 0; i < f->spk; ++i) en[i] = embedding[i] / nrm;
+    }
+    HIPCHK(hipMemcpyAsync(f->ids.p, ids.data(), (size_t)T * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(f->spk_in.p, en.data(), en.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(t3k::launch_embed_rows(f->embedding, static_cast<const int*>(f->ids.p), nullptr, f->x0.f(), T, f->d, st));
+    if ((rc = encoder_rows(m, T))) return rc;                                                      // :839
+    int T2 = 2 * T;
+    if (!finalize) T2 -= 3 * 2;                                                                    // pre_lookahead_len * token_mel_ratio, :844-846
+    const int mel_len1 = 2 * n_prompt, mel_len2 = T2 - mel_len1;
+    if (mel_len2 <= 0) return fail(T3MI_ERR_ARG, "t3mi_flow_inference: nothing left to generate after the prompt");
+    if (cap_frames < mel_len2) return fail(T3MI_ERR_ARG, "t3mi_flow_inference: output holds fewer than " + std::to_string(mel_len2) + " frames");
+    if (noise_T < T2) return fail(T3MI_ERR_ARG, "t3mi_flow_inference: the noise must cover " + std::to_string(T2) + " frames");
+    if ((rc = fgemm(m, f->xn.f(), f->enc_proj, T2, t3k::EPI_STORE, f->mu.f(), nullptr))) return rc;   // encoder_proj, :854
+    if ((rc = fgemm(m, f->spk_in.f(), f->spk_affine, 1, t3k::EPI_STORE, f->spk_out.f(), nullptr))) return rc;
+    std::vector<float> mu_rows((size_t)T2 * mel), spk((size_t)mel);
+    HIPCHK(hipMemcpyAsync(mu_rows.data(), f->mu.p, mu_rows.size() * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(spk.data(), f->spk_out.p, spk.size() * 4, hipMemcpyDeviceToHost, st));
+    float enc_ms = 0.f;
+    if (device_ms) {
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipEventElapsedTime(&enc_ms, e0, e1));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    // decoder inputs in the reference's layouts (R/s3gen.R:857-883): mu (1, mel, T2); conds = the prompt mel over its frames
+    std::vector<float> mu((size_t)mel * T2), cond((size_t)mel * T2, 0.f), mask((size_t)T2, 1.0f), z((size_t)mel * T2), res((size_t)mel * T2);
+    const int nc = std::min(n_feat, mel_len1);
+    for (int c = 0; c < mel; ++c)
+        for (int t = 0; t < T2; ++t) {
+            mu[(size_t)c * T2 + t] = mu_rows[(size_t)t * mel + c];
+            if (t < nc) cond[(size_t)c * T2 + t] = prompt_feat[(size_t)t * mel + c];
+            z[(size_t)c * T2 + t] = noise[(size_t)c * noise_T + t];
+        }
+    float solve_ms = 0.f;
+    rc = t3mi_cfm_solve(m, T2, z.data(), mu.data(), mask.data(), spk.data(), cond.data(), n_timesteps, cfg_rate, meanflow, res.data(),
+                        device_ms ? &solve_ms : nullptr);
+    if (rc) return rc;
+    for (int c = 0; c < mel; ++c)                                                                    // feat[,, (mel_len1 + 1):...], :887
+        std::memcpy(out + (size_t)c * mel_len2, res.data() + (size_t)c * T2 + mel_len1, (size_t)mel_len2 * 4);
+    *n_frames = mel_len2;
+    if (device_ms) *device_ms = enc_ms + solve_ms;
     return T3MI_OK;
 }
 

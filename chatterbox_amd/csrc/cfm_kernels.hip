@@ -39,10 +39,14 @@ __device__ __forceinline__ float mish_f(float x) {
 // 16-query wave is the unit of work and a 500-frame CFG pair has only 512 of them for 1024 SIMDs: split `sp` takes key
 // tiles [sp * tps, (sp + 1) * tps) and leaves an unnormalised partial (o, running max, sum) that cfm_attn_merge_kernel
 // combines in a fixed order; n_split == 1 writes the normalised rows directly.
-template <int NW>
+// REL (the conformer's rel_position_attention, R/conformer.R:226-279): q gets pos_bias_u added on load and every score gets
+// the position term bd[head][query][T - 1 - query + key] (conf_bd_kernel's product, read through rel_shift's index map,
+// R/conformer.R:281-307) before the 1 / sqrt(d_k) scale.
+template <int NW, bool REL>
 __global__ __launch_bounds__(64 * NW) void cfm_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int ld,
                                                            int inner, float scale, int n_split, int tps, float* __restrict__ po,
-                                                           float* __restrict__ pml, int M_total) {
+                                                           float* __restrict__ pml, int M_total, const float* __restrict__ qbias,
+                                                           const float* __restrict__ bd) {
     __shared__ __attribute__((aligned(16))) float kt_s[64 * kLd];
     __shared__ __attribute__((aligned(16))) float vt_s[64 * kLd];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -56,6 +60,12 @@ __global__ __launch_bounds__(64 * NW) void cfm_attn_kernel(const float* __restri
     f32x4 qv[4];   // native vectors: arrays of HIP's float4 struct can end up in scratch memory
 #pragma unroll
     for (int i = 0; i < 4; ++i) qv[i] = *reinterpret_cast<const f32x4*>(qp + 16 * i);
+    if (REL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qv[i] += *reinterpret_cast<const f32x4*>(qbias + head * kDh + 4 * g + 16 * i);   // q + pos_bias_u
+    }
+    // row of this lane's query in the position product: entry (T - 1 - query) + key
+    const float* bdq = REL ? bd + ((size_t)head * T + qi) * (size_t)(2 * T - 1) + (T - 1 - qi) : nullptr;
     const float* kbase = qkv + row0 * ld + inner + head * kDh;
     const float* vbase = kbase + inner;
 
@@ -87,6 +97,13 @@ __global__ __launch_bounds__(64 * NW) void cfm_attn_kernel(const float* __restri
         __syncthreads();
         prefetch(j + 1 < n_tiles ? j + 1 : j);   // unconditional (clamped): the compiler can count the loads in flight
         f32x4 s[4];
+        float pb[4][4];
+        if (REL) {   // requested before the MFMAs that hide them; keys past the end are clamped (masked below)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pb[kt][r] = bdq[min(j * 64 + 16 * kt + 4 * g + r, T - 1)];
+        }
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -105,7 +122,8 @@ __global__ __launch_bounds__(64 * NW) void cfm_attn_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = j * 64 + 16 * kt + 4 * g + r;
-                const float v = key < T ? s[kt][r] * scale : -INFINITY;   // R/s3gen.R:276
+                const float raw = REL ? s[kt][r] + pb[kt][r] : s[kt][r];       // matrix_ac + matrix_bd, R/conformer.R:257
+                const float v = key < T ? raw * scale : -INFINITY;             // R/s3gen.R:276
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -276,11 +294,84 @@ __global__ __launch_bounds__(256) void cfm_mask_rows_kernel(const float* __restr
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) out[e] = x[e] * mask[e / C];
 }
 
-// mode 0: silu (timestep_embedding, R/s3gen.R:111), 1: mish (resnet mlp, R/s3gen.R:210-213)
-__global__ __launch_bounds__(256) void cfm_act_kernel(const float* __restrict__ x, float* __restrict__ out, size_t n, int mode) {
+// mode 0: silu (timestep_embedding, R/s3gen.R:111; conformer feed-forward, R/conformer.R:336), 1: mish (resnet mlp,
+// R/s3gen.R:210-213), 2: leaky_relu with slope 0.01 (pre_lookahead_layer, R/conformer.R:172), 3: * arg (xscale, R/conformer.R:90)
+__global__ __launch_bounds__(256) void cfm_act_kernel(const float* __restrict__ x, float* __restrict__ out, size_t n, int mode, float arg) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
         const float v = x[e];
-        out[e] = mode == 0 ? v / (1.0f + expf(-v)) : mish_f(v);
+        float y;
+        if (mode == 0) y = v / (1.0f + expf(-v));
+        else if (mode == 1) y = mish_f(v);
+        else if (mode == 2) y = v >= 0.f ? v : v * 0.01f;
+        else y = v * arg;
+        out[e] = y;
+    }
+}
+
+// ---- conformer pieces ---------------------------------------------------------------------------------------------
+// k-tap window rows of one sequence for a convolution as a GEMM: col[t][j * C + c] = xs[(t + j + off) / up][c] where
+// 0 <= t + j + off < T_in * up, else 0.  off = 0: right-padded look-ahead conv (R/conformer.R:168-172); off = -(k - 1):
+// left-padded causal conv (:175-178); up = 2, off = -4, k = 5: nearest-neighbour x 2 then the left-padded conv (:432-438).
+__global__ __launch_bounds__(256) void rows_window_kernel(const float* __restrict__ x, float* __restrict__ col, int T_out, int T_in, int C,
+                                                          int k, int off, int up) {
+    const int n4 = C >> 2;
+    const size_t total = (size_t)T_out * k * n4;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(e % n4);
+        const size_t tj = e / n4;
+        const int j = (int)(tj % k), t = (int)(tj / k);
+        const int sidx = t + j + off;
+        float4 v{0.f, 0.f, 0.f, 0.f};
+        if (sidx >= 0 && sidx < T_in * up) v = *reinterpret_cast<const float4*>(x + (size_t)(sidx / up) * C + 4 * c4);
+        *reinterpret_cast<float4*>(col + ((size_t)t * k + j) * C + 4 * c4) = v;
+    }
+}
+
+// espnet_rel_positional_encoding (R/conformer.R:34-95): rows for the relative positions +(T - 1) .. -(T - 1):
+// pe[n][2 i] = sin(rel * div_i), pe[n][2 i + 1] = cos(rel * div_i), rel = T - 1 - n, div_i = exp(2 i * -(log(1e4) / d))
+__global__ __launch_bounds__(256) void rel_pos_emb_kernel(float* __restrict__ pe, int T, int d) {
+    const int half = d >> 1, P = 2 * T - 1;
+    const float c = (float)(-(9.210340371976184 / (double)d));
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < P * half; e += gridDim.x * 256) {
+        const int n = e / half, i = e % half;
+        const float ang = (float)(T - 1 - n) * expf((float)(2 * i) * c);
+        pe[(size_t)n * d + 2 * i] = sinf(ang);
+        pe[(size_t)n * d + 2 * i + 1] = cosf(ang);
+    }
+}
+
+// matrix_bd before rel_shift (R/conformer.R:253): bd[h][q][n] = (q[q] + pos_bias_v)[h] . p[n][h], n < 2T - 1.
+// One wave per (16 queries, 64 positions, head): K = 64 in 16 exact-fp32 MFMA steps, operands straight from L2.
+__global__ __launch_bounds__(64) void conf_bd_kernel(const float* __restrict__ qkv, int ld, const float* __restrict__ bias_v,
+                                                     const float* __restrict__ p, int d, float* __restrict__ bd, int T) {
+    const int lane = threadIdx.x, nl = lane & 15, g = lane >> 4;
+    const int P = 2 * T - 1, n0 = blockIdx.x * 64, q0 = blockIdx.y * 16, head = blockIdx.z;
+    const float* qp = qkv + (size_t)min(q0 + nl, T - 1) * ld + head * kDh + 4 * g;
+    const float* bp = bias_v + head * kDh + 4 * g;
+    f32x4 av[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f32x4*>(qp + 16 * i) + *reinterpret_cast<const f32x4*>(bp + 16 * i);
+    f32x4 acc[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const float* pr = p + (size_t)min(n0 + 16 * pt + nl, P - 1) * d + head * kDh + 4 * g;
+        f32x4 bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(pr + 16 * i);
+        acc[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][c], bv[i][c], acc[pt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const int n = n0 + 16 * pt + nl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = q0 + 4 * g + r;
+            if (q < T && n < P) bd[((size_t)head * T + q) * P + n] = acc[pt][r];
+        }
     }
 }
 
@@ -327,8 +418,9 @@ int cfm_attn_splits(int n_seq, int T, int heads) {
 }
 
 hipError_t launch_cfm_attn(const float* qkv, float* out, int n_seq, int T, int heads, int head_dim, float* part_o, float* part_ml,
-                           hipStream_t s) {
+                           hipStream_t s, const float* qbias, const float* bd) {
     if (!qkv || !out || n_seq <= 0 || T <= 0 || heads <= 0 || head_dim != kDh) return hipErrorInvalidValue;
+    if ((qbias == nullptr) != (bd == nullptr) || (bd != nullptr && n_seq != 1)) return hipErrorInvalidValue;
     const int inner = heads * kDh, ld = 3 * inner, M = n_seq * T;
     const float scale = 1.0f / sqrtf((float)head_dim);
     const int n_tiles = (T + 63) / 64;
@@ -336,12 +428,17 @@ hipError_t launch_cfm_attn(const float* qkv, float* out, int n_seq, int T, int h
     const int tps = (n_tiles + ns - 1) / ns;
     // 16 NW queries per block: the narrower block when the wider one would leave CUs idle
     const long long blocks4 = (long long)((T + 63) / 64) * heads * n_seq * ns;
-    if (blocks4 >= 512)
-        hipLaunchKernelGGL(cfm_attn_kernel<4>, dim3(((T + 63) / 64) * ns, heads, n_seq), dim3(256), 0, s, qkv, out, T, ld, inner, scale, ns, tps,
-                           part_o, part_ml, M);
-    else
-        hipLaunchKernelGGL(cfm_attn_kernel<2>, dim3(((T + 31) / 32) * ns, heads, n_seq), dim3(128), 0, s, qkv, out, T, ld, inner, scale, ns, tps,
-                           part_o, part_ml, M);
+    const dim3 g4(((T + 63) / 64) * ns, heads, n_seq), g2(((T + 31) / 32) * ns, heads, n_seq);
+    if (bd != nullptr) {
+        if (blocks4 >= 512)
+            hipLaunchKernelGGL((cfm_attn_kernel<4, true>), g4, dim3(256), 0, s, qkv, out, T, ld, inner, scale, ns, tps, part_o, part_ml, M, qbias, bd);
+        else
+            hipLaunchKernelGGL((cfm_attn_kernel<2, true>), g2, dim3(128), 0, s, qkv, out, T, ld, inner, scale, ns, tps, part_o, part_ml, M, qbias, bd);
+    } else if (blocks4 >= 512) {
+        hipLaunchKernelGGL((cfm_attn_kernel<4, false>), g4, dim3(256), 0, s, qkv, out, T, ld, inner, scale, ns, tps, part_o, part_ml, M, qbias, bd);
+    } else {
+        hipLaunchKernelGGL((cfm_attn_kernel<2, false>), g2, dim3(128), 0, s, qkv, out, T, ld, inner, scale, ns, tps, part_o, part_ml, M, qbias, bd);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || ns == 1) return e;
     hipLaunchKernelGGL(cfm_attn_merge_kernel, dim3(grid_for((size_t)M * (inner >> 2))), dim3(256), 0, s, part_o, part_ml, out, M, inner, ns);
@@ -373,9 +470,27 @@ hipError_t launch_cfm_mask_rows(const float* x, const float* mask, float* out, i
     return hipGetLastError();
 }
 
-hipError_t launch_cfm_act(const float* x, float* out, size_t n, int mode, hipStream_t s) {
-    if (!x || !out || n == 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(cfm_act_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, out, n, mode);
+hipError_t launch_cfm_act(const float* x, float* out, size_t n, int mode, hipStream_t s, float arg) {
+    if (!x || !out || n == 0 || mode < 0 || mode > 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cfm_act_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, out, n, mode, arg);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_window(const float* x, float* col, int T_out, int T_in, int C, int k, int off, int up, hipStream_t s) {
+    if (!x || !col || T_out <= 0 || T_in <= 0 || C <= 0 || (C & 3) || k <= 0 || up <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rows_window_kernel, dim3(grid_for((size_t)T_out * k * (C >> 2))), dim3(256), 0, s, x, col, T_out, T_in, C, k, off, up);
+    return hipGetLastError();
+}
+
+hipError_t launch_rel_pos_emb(float* pe, int T, int d, hipStream_t s) {
+    if (!pe || T <= 0 || d < 2 || (d & 1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rel_pos_emb_kernel, dim3(grid_for((size_t)(2 * T - 1) * (d >> 1))), dim3(256), 0, s, pe, T, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_conf_bd(const float* qkv, int ld, const float* bias_v, const float* p, int d, float* bd, int T, int heads, hipStream_t s) {
+    if (!qkv || !bias_v || !p || !bd || T <= 0 || heads <= 0 || d != heads * kDh) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(conf_bd_kernel, dim3((2 * T - 1 + 63) / 64, (T + 15) / 16, heads), dim3(64), 0, s, qkv, ld, bias_v, p, d, bd, T);
     return hipGetLastError();
 }
 

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["CfmEstimator", "load_cfm_estimator", "causal_cfm_forward"]
+__all__ = ["CfmEstimator", "load_cfm_estimator", "causal_cfm_forward", "S3GenFlow", "load_s3gen_flow"]
 
 _FP = C.POINTER(C.c_float)
 
@@ -97,3 +97,63 @@ def causal_cfm_forward(estimator: CfmEstimator, mu, mask, spks, cond, noise, n_t
     if timing is not None:
         timing["device_ms"] = float(ms.value)
     return out
+
+
+class S3GenFlow(CfmEstimator):
+    """`causal_masked_diff_xvec` with load_s3gen_weights' flow part applied (R/s3gen.R:768-891, 1215-1231): token embedding,
+    speaker projection, the upsampling conformer encoder, encoder projection and the CFM decoder, resident on one MI355X.
+    Also a CfmEstimator (its `forward` and causal_cfm_forward work on it)."""
+
+    def __init__(self, path: str, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.t3mi_flow_open(path.encode(), int(device), C.byref(h)))
+        self._h = h
+        info = _lib.CfmInfo()
+        _lib.check(self._lib.t3mi_cfm_get_info(self._h, C.byref(info)))
+        self.info = info
+        self.mel, self.meanflow = int(info.mel), bool(info.meanflow)
+        fi = _lib.FlowInfo()
+        _lib.check(self._lib.t3mi_flow_get_info(self._h, C.byref(fi)))
+        self.flow_info = fi
+
+    def encoder(self, x) -> np.ndarray:
+        """upsample_conformer_encoder_full$forward (R/conformer.R:517-578) for one sequence: x [T, d] -> [2T, d]."""
+        x = _f32(x)
+        T, d = x.shape
+        if d != self.flow_info.d_model:
+            raise ValueError(f"x must be [T, {self.flow_info.d_model}]")
+        out = np.empty((2 * T, d), dtype=np.float32)
+        _lib.check(self._lib.t3mi_flow_encoder(self._h, T, _p(x), _p(out)))
+        return out
+
+    def inference(self, token, prompt_token, prompt_feat, embedding, noise, finalize: bool = True, n_timesteps: Optional[int] = None,
+                  inference_cfg_rate: float = 0.7, meanflow: Optional[bool] = None, timing: Optional[dict] = None) -> np.ndarray:
+        """causal_masked_diff_xvec$forward(token, ..., prompt_token, ..., prompt_feat, ..., embedding, finalize, n_timesteps)
+        (R/s3gen.R:805-890) for one utterance: 0-indexed speech tokens -> mel (1, mel, 2 * len(token)) of the generated part.
+        `noise` (1, mel, >= 2 * (len(prompt_token) + len(token))): see causal_cfm_forward."""
+        tok = np.ascontiguousarray(np.reshape(token, -1), dtype=np.int32)
+        ptok = np.ascontiguousarray(np.reshape(prompt_token, -1), dtype=np.int32)
+        pf = _f32(prompt_feat).reshape(-1, self.mel)
+        emb = _f32(np.reshape(embedding, -1), (self.flow_info.spk_embed_dim,))
+        z = _f32(noise)
+        if z.ndim != 3 or z.shape[:2] != (1, self.mel):
+            raise ValueError(f"noise must be (1, {self.mel}, frames)")
+        use_mf = self.meanflow if meanflow is None else bool(meanflow)
+        steps = int(n_timesteps) if n_timesteps is not None else (2 if use_mf else 10)        # R/s3gen.R:873, :1017
+        cap = 2 * tok.size
+        out = np.empty((1, self.mel, cap), dtype=np.float32)
+        n = C.c_int(0)
+        ms = C.c_float(0)
+        IP = C.POINTER(C.c_int32)
+        _lib.check(self._lib.t3mi_flow_inference(self._h, tok.ctypes.data_as(IP), tok.size, ptok.ctypes.data_as(IP), ptok.size, _p(pf),
+                                                 pf.shape[0], _p(emb), _p(z), z.shape[2], steps, float(inference_cfg_rate),
+                                                 1 if use_mf else 0, 1 if finalize else 0, _p(out), cap, C.byref(n), C.byref(ms)))
+        if timing is not None:
+            timing["device_ms"] = float(ms.value)
+        # the C side packs rows of n frames
+        return out.reshape(-1)[: self.mel * n.value].reshape(1, self.mel, n.value).copy()
+
+
+def load_s3gen_flow(path: str, device: int = 0) -> S3GenFlow:
+    return S3GenFlow(path, device)

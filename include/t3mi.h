@@ -265,6 +265,32 @@ int t3mi_cfm_estimator(t3mi_cfm* m, int B, int T, const float* x, const float* m
 int t3mi_cfm_solve(t3mi_cfm* m, int T, const float* z, const float* mu, const float* mask, const float* spks, const float* cond,
                    int n_timesteps, double cfg_rate, int meanflow, float* out, float* device_ms);
 
+
+/* ---- the flow module in front of the estimator: speech tokens -> mel (second piece) -----------------------
+ * causal_masked_diff_xvec (R/s3gen.R:768-891): input_embedding, spk_embed_affine_layer, the upsampling conformer encoder
+ * (upsample_conformer_encoder_full, R/conformer.R:464-593: linear_no_subsampling, pre_lookahead_layer, 6 + 4
+ * conformer_encoder_layers with rel_position_attention, upsample_1d), encoder_proj, then causal_cfm.  One utterance per
+ * call, every position valid -- what s3gen$inference passes (R/s3gen.R:1006-1011). */
+typedef struct t3mi_flow_info {
+    int32_t vocab, d_model, heads, d_ff, n_blocks, n_up_blocks, spk_embed_dim, mel;
+    int64_t weight_bytes;
+} t3mi_flow_info;
+/* load_s3gen_weights' flow part (R/s3gen.R:1215-1231; load_conformer_encoder_weights R/conformer.R:604-716) from the unchanged
+ * s3gen safetensors file; the handle also serves t3mi_cfm_estimator / t3mi_cfm_solve. */
+int t3mi_flow_open(const char* safetensors_path, int device, t3mi_cfm** out);
+int t3mi_flow_get_info(const t3mi_cfm* m, t3mi_flow_info* info);
+/* upsample_conformer_encoder_full$forward (R/conformer.R:517-578), parity hook: x [T, d_model] (embedded tokens), out [2T, d_model]. */
+int t3mi_flow_encoder(t3mi_cfm* m, int T, const float* x, float* out);
+/* causal_masked_diff_xvec$forward (R/s3gen.R:805-890): token / prompt_token are 0-indexed ids; prompt_feat [n_feat, mel] (the
+ * reference mel, truncated or zero-padded to 2 * n_prompt frames, :857-865); embedding [spk_embed_dim] (the x-vector);
+ * noise (1, mel, noise_T), noise_T >= 2 * (n_prompt + n_token) (see t3mi_cfm_solve); finalize = 0 drops the 6 look-ahead
+ * frames (:844-846).  out (1, mel, *n_frames) = the generated part, *n_frames = 2 * n_token (- 6).  device_ms (may be
+ * NULL): HIP-event time of the encoder and the solve. */
+int t3mi_flow_inference(t3mi_cfm* m, const int32_t* token, int n_token, const int32_t* prompt_token, int n_prompt,
+                        const float* prompt_feat, int n_feat, const float* embedding, const float* noise, int noise_T,
+                        int n_timesteps, double cfg_rate, int meanflow, int finalize, float* out, int cap_frames, int* n_frames,
+                        float* device_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,3 +124,71 @@ def test_cfm_rejects_bad_input(tmp_path):
     with pytest.raises(_lib.T3miError) as e:
         cb.load_cfm_estimator(bad)
     assert e.value.code == _lib.ERR_IO and "ff.net.2.bias" in str(e.value)
+
+
+# ---- the flow module in front of the estimator: conformer encoder, tokens -> mel (R/conformer.R, R/s3gen.R:805-890) ------
+
+@pytest.mark.parametrize("dims,T", [(synth.FLOW_TINY, 23), (synth.FLOW_TINY, 150), (synth.FlowDims(n_blocks=2, n_up=1, cfm=synth.CFM_TINY), 77)],
+                         ids=["tiny-23", "tiny-150", "full-width-77"])
+def test_conformer_encoder_matches_the_oracle(dims, T):
+    """upsample_conformer_encoder_full$forward: linear_no_subsampling, the look-ahead convs, rel_position_attention with
+    pos_bias_u / pos_bias_v and rel_shift, nearest x 2 + conv upsampling; T not a multiple of any tile."""
+    w = synth.synth_flow_weights(dims, 555)
+    x = np.random.default_rng(2).standard_normal((T, dims.d)).astype(np.float32)
+    want = S.ConformerOracle(w, heads=dims.heads).forward(x)
+    with cb.load_s3gen_flow(synth.ensure_flow_checkpoint(dims, 555)) as flow:
+        fi = flow.flow_info
+        assert (fi.d_model, fi.heads, fi.n_blocks, fi.n_up_blocks, fi.vocab) == (dims.d, dims.heads, dims.n_blocks, dims.n_up, dims.vocab)
+        got = flow.encoder(x)
+        again = flow.encoder(x)
+    assert got.shape == (2 * T, dims.d) and np.isfinite(got).all()
+    assert _rel(got, want) < TOL, _rel(got, want)
+    assert np.array_equal(got, again)
+
+
+def test_full_size_conformer_encoder_matches_the_oracle():
+    """The real encoder (512 wide, 8 heads, 6 + 4 layers, ffn 2048, R/s3gen.R:41-53) on 120 tokens -> 240 frames."""
+    dims = synth.FlowDims(cfm=synth.CFM_TINY)
+    T = 120
+    w = synth.synth_flow_weights(dims, 555)
+    x = w["flow.input_embedding.weight"][np.random.default_rng(5).integers(0, dims.vocab, T)]
+    want = S.ConformerOracle(w, heads=dims.heads).forward(x)
+    with cb.load_s3gen_flow(synth.ensure_flow_checkpoint(dims, 555)) as flow:
+        got = flow.encoder(x)
+    assert _rel(got, want) < TOL, _rel(got, want)
+
+
+@pytest.mark.parametrize("finalize", [True, False])
+def test_flow_inference_matches_the_oracle(finalize):
+    """causal_masked_diff_xvec$forward end to end: tokens + prompt tokens + prompt mel + x-vector -> mel of the generated part
+    (10 Euler steps with guidance), with and without the look-ahead truncation of finalize = FALSE; a prompt mel shorter
+    than 2 x prompt tokens is zero-padded (R/s3gen.R:857-865)."""
+    dims = synth.FLOW_TINY
+    w = synth.synth_flow_weights(dims, 555)
+    tok, ptok, pfeat, xvec, z = synth.synth_flow_inputs(dims, 21, 13, 4)
+    pfeat = pfeat[:20]                                   # shorter than mel_len1 = 26
+    want = S.flow_inference(w, tok, ptok, pfeat, xvec, z, n_timesteps=10, heads=dims.heads, cfm_heads=dims.cfm.heads, finalize=finalize)
+    tm = {}
+    with cb.load_s3gen_flow(synth.ensure_flow_checkpoint(dims, 555)) as flow:
+        got = flow.inference(tok, ptok, pfeat, xvec, z, finalize=finalize, timing=tm)
+        # out-of-range ids are clamped to the table (R/s3gen.R:833)
+        t2 = tok.copy(); t2[3] = dims.vocab + 50
+        t3 = tok.copy(); t3[3] = dims.vocab - 1
+        assert np.array_equal(flow.inference(t2, ptok, pfeat, xvec, z, finalize=finalize), flow.inference(t3, ptok, pfeat, xvec, z, finalize=finalize))
+    assert got.shape == want.shape == (1, dims.cfm.mel, 42 - (0 if finalize else 6)) and tm["device_ms"] > 0
+    assert _rel(got, want) < TOL, _rel(got, want)
+
+
+def test_flow_rejects_bad_input():
+    with pytest.raises(_lib.T3miError) as e:             # an estimator-only checkpoint is not a flow checkpoint
+        cb.load_s3gen_flow(synth.ensure_cfm_checkpoint(synth.CFM_TINY, 777))
+    assert e.value.code == _lib.ERR_IO
+    dims = synth.FLOW_TINY
+    with cb.load_s3gen_flow(synth.ensure_flow_checkpoint(dims, 555)) as flow:
+        tok, ptok, pfeat, xvec, z = synth.synth_flow_inputs(dims, 8, 4, 1)
+        with pytest.raises(_lib.T3miError) as e:
+            flow.inference(tok, ptok, pfeat, xvec, z[:, :, :10])          # noise shorter than the sequence
+        assert e.value.code == _lib.ERR_ARG and "noise" in str(e.value)
+    with cb.load_cfm_estimator(synth.ensure_cfm_checkpoint(synth.CFM_TINY, 777)) as est:
+        rc = est._lib.t3mi_flow_encoder(est._h, 4, None, None)
+        assert rc == _lib.ERR_STATE
