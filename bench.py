@@ -515,6 +515,8 @@ def run(args, world, rank, local_rank):
                 sys.path.insert(0, os.path.join(ROOT, "scripts"))
                 import bench_cfm
                 attach["cfm_solve"] = bench_cfm.run(frames=500, steps=10, reps=3)
+                import bench_s3gen
+                attach["s3gen"] = bench_s3gen.run(tokens=100, prompt=150, reps=2)
             except Exception as e:
                 attach["cfm_solve_error"] = f"{type(e).__name__}: {e}"
 

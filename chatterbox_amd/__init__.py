@@ -7,6 +7,7 @@ from .t3 import (SPEECH_VOCAB_SIZE, Session, T3Cond, T3Model, drop_invalid_token
                  prepare_input_embeds, split_sentences, t3_cond, t3_inference, t3_inference_batch, t3_inference_cpp,
                  t3_inference_traced, t3_inference_turbo, t3_inference_turbo_batch, tts_chunked)
 
-from .s3gen import CfmEstimator, S3GenFlow, causal_cfm_forward, load_cfm_estimator, load_s3gen_flow  # noqa: F401,E402
+from .s3gen import (CfmEstimator, HiftVocoder, S3GenFlow, causal_cfm_forward, load_cfm_estimator, load_hift_vocoder,  # noqa: F401,E402
+                    load_s3gen_flow, s3gen_inference)  # noqa: F401,E402
 
 __version__ = "0.1.0"

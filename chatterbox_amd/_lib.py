@@ -63,6 +63,11 @@ class FlowInfo(C.Structure):
                [("weight_bytes", C.c_int64)]
 
 
+class HiftInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("mel", "base_channels", "f0_channels", "n_harmonics", "samples_per_frame", "sampling_rate",
+                                         "device", "reserved_")] + [("weight_bytes", C.c_int64)]
+
+
 class KStat(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_int32), ("total_us", C.c_float),
                 ("bytes", C.c_double)]
@@ -117,6 +122,10 @@ SYMBOLS = {
     "t3mi_flow_encoder": (C.c_int, [_H, C.c_int, _FP, _FP]),
     "t3mi_flow_inference": (C.c_int, [_H, _IP, C.c_int, _IP, C.c_int, _FP, C.c_int, _FP, _FP, C.c_int, C.c_int, C.c_double, C.c_int,
                                       C.c_int, _FP, C.c_int, C.POINTER(C.c_int), _FP]),
+    "t3mi_hift_open": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_H)]),
+    "t3mi_hift_close": (C.c_int, [_H]),
+    "t3mi_hift_get_info": (C.c_int, [_H, C.POINTER(HiftInfo)]),
+    "t3mi_hift_inference": (C.c_int, [_H, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
     "t3mi_cfm_solve": (C.c_int, [_H, C.c_int, _FP, _FP, _FP, _FP, _FP, C.c_int, C.c_double, C.c_int, _FP, _FP]),
 }
 

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["CfmEstimator", "load_cfm_estimator", "causal_cfm_forward", "S3GenFlow", "load_s3gen_flow"]
+__all__ = ["CfmEstimator", "load_cfm_estimator", "causal_cfm_forward", "S3GenFlow", "load_s3gen_flow", "HiftVocoder", "load_hift_vocoder", "s3gen_inference", "trim_fade"]
 
 _FP = C.POINTER(C.c_float)
 
@@ -157,3 +157,90 @@ class S3GenFlow(CfmEstimator):
 
 def load_s3gen_flow(path: str, device: int = 0) -> S3GenFlow:
     return S3GenFlow(path, device)
+
+
+class HiftVocoder:
+    """`hift_generator` as create_s3gen_vocoder builds it, with load_hifigan_weights applied (R/hifigan.R:337-817), resident
+    on one MI355X."""
+
+    def __init__(self, path: str, device: int = 0, prefix: str = "mel2wav."):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.t3mi_hift_open(path.encode(), prefix.encode(), int(device), C.byref(h)))
+        self._h = h
+        info = _lib.HiftInfo()
+        _lib.check(self._lib.t3mi_hift_get_info(self._h, C.byref(info)))
+        self.info = info
+        self.mel, self.n_harmonics, self.samples_per_frame = int(info.mel), int(info.n_harmonics), int(info.samples_per_frame)
+
+    def inference(self, speech_feat, phase=None, noise=None, timing: Optional[dict] = None) -> dict:
+        """hift_generator$inference(speech_feat) (R/hifigan.R:601-626): speech_feat (1, mel, T) or (mel, T) -> {"audio": [480 T],
+        "source": [480 T], "f0": [T]}.  phase [n_harmonics] / noise [n_harmonics, 480 T]: the draws the reference takes from
+        torch's generator (R/hifigan.R:237-249); None = zero phases / no noise term."""
+        m = _f32(speech_feat)
+        if m.ndim == 3:
+            m = m[0]
+        mel, T = m.shape
+        if mel != self.mel:
+            raise ValueError(f"speech_feat must have {self.mel} mel bins")
+        m = np.ascontiguousarray(m)
+        n = T * self.samples_per_frame
+        ph = None if phase is None else _f32(np.reshape(phase, -1), (self.n_harmonics,))
+        nz = None if noise is None else _f32(noise, (self.n_harmonics, n))
+        audio, src, f0 = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(T, np.float32)
+        ms = C.c_float(0)
+        _lib.check(self._lib.t3mi_hift_inference(self._h, T, _p(m), _p(ph), _p(nz), _p(audio), _p(src), _p(f0), C.byref(ms)))
+        if timing is not None:
+            timing["device_ms"] = float(ms.value)
+        return {"audio": audio, "source": src, "f0": f0}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.t3mi_hift_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def load_hift_vocoder(path: str, device: int = 0, **kw) -> HiftVocoder:
+    return HiftVocoder(path, device, **kw)
+
+
+S3GEN_SR = 24000      # R/s3gen.R:5
+
+
+def trim_fade(sr: int = S3GEN_SR) -> np.ndarray:
+    """s3gen's fade-in buffer (R/s3gen.R:922-927): 20 ms of zeros, then 20 ms of a raised-cosine ramp."""
+    n_trim = sr // 50
+    fade = np.zeros(2 * n_trim, dtype=np.float32)
+    fade[n_trim:] = ((np.cos(np.linspace(np.pi, 0.0, n_trim, dtype=np.float32)) + np.float32(1)) / np.float32(2)).astype(np.float32)
+    return fade
+
+
+def s3gen_inference(flow: S3GenFlow, vocoder: HiftVocoder, speech_tokens, ref_dict: dict, noise, phase=None, source_noise=None,
+                    finalize: bool = True, n_cfm_timesteps: Optional[int] = None, timing: Optional[dict] = None):
+    """s3gen$inference(speech_tokens, ref_dict = ..., finalize, n_cfm_timesteps) (R/s3gen.R:987-1056): speech tokens -> mel (flow)
+    -> waveform (HiFT) -> fade-in.  ref_dict carries what embed_ref returns (R/s3gen.R:977-983): prompt_token, prompt_feat
+    [frames, 80], embedding [192].  `noise` feeds the CFM solve, `phase` / `source_noise` the vocoder's source (the draws the
+    reference takes from torch's generator).  Returns (audio [T_wav], mel (1, 80, T))."""
+    t_flow, t_voc = {}, {}
+    mel = flow.inference(speech_tokens, ref_dict["prompt_token"], ref_dict["prompt_feat"], ref_dict["embedding"], noise,
+                         finalize=finalize, n_timesteps=n_cfm_timesteps, timing=t_flow)
+    out = vocoder.inference(mel, phase, source_noise, timing=t_voc)
+    audio = out["audio"]
+    fade = trim_fade()
+    n = min(fade.size, audio.size)
+    audio[:n] = audio[:n] * fade[:n]                               # R/s3gen.R:1047-1049
+    if timing is not None:
+        timing.update(flow_ms=t_flow.get("device_ms"), vocoder_ms=t_voc.get("device_ms"))
+    return audio, mel

@@ -432,3 +432,97 @@ def synth_flow_inputs(dims: FlowDims, n_tokens: int, n_prompt: int, seed: int):
     xvec = rng.standard_normal(dims.spk, dtype=F32)
     z = rng.standard_normal((1, mel, 2 * (n_prompt + n_tokens)), dtype=F32)
     return tok, ptok, pfeat, xvec, z
+
+
+# ---- HiFT vocoder (third piece) -----------------------------------------------------------------------
+
+@dataclass(frozen=True)
+class HiftDims:
+    """hift_generator as create_s3gen_vocoder configures it (R/hifigan.R:788-817); base_channels reducible for tests."""
+    mel: int = 80
+    base: int = 512
+    f0_ch: int = 512
+    n_harm: int = 9              # nb_harmonics 8 + the fundamental
+    n_fft: int = 16
+
+
+HIFT_FULL = HiftDims()
+HIFT_TINY = HiftDims(mel=16, base=64, f0_ch=64)
+HIFT_UPS = ((8, 16), (5, 11), (3, 7))
+HIFT_RES_K = (3, 7, 11)
+HIFT_SRC_K = (7, 7, 11)
+
+
+def synth_hift_weights(dims: HiftDims = HIFT_FULL, seed: int = 999, prefix: str = "mel2wav.") -> Dict[str, np.ndarray]:
+    """A synthetic vocoder checkpoint under the keys load_hifigan_weights reads (R/hifigan.R:640-777): weight-normalised
+    convolutions as `parametrizations.weight.original0 / original1` pairs (g [out, 1, 1], v [out, in, k]; conv-transpose:
+    g [in, 1, 1], v [in, out, k]), plain tensors for source_downs, the linears and the Snake alphas."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    w: Dict[str, np.ndarray] = {}
+
+    def pconv(name, a, b, k, gain=0.8):       # v [a, b, k]; effective row norm = g
+        v = rng.standard_normal((a, b, k), dtype=F32)
+        g = (F32(gain) * (F32(1) + F32(0.2) * rng.standard_normal((a, 1, 1), dtype=F32))).astype(F32)
+        w[prefix + name + ".parametrizations.weight.original0"] = np.abs(g).astype(F32)
+        w[prefix + name + ".parametrizations.weight.original1"] = v
+        return name
+
+    def bias(name, n, std=0.05):
+        w[prefix + name + ".bias"] = (rng.standard_normal(n, dtype=F32) * F32(std)).astype(F32)
+
+    c = dims.f0_ch
+    for i in range(5):
+        pconv(f"f0_predictor.condnet.{2 * i}", c, dims.mel if i == 0 else c, 3)
+        bias(f"f0_predictor.condnet.{2 * i}", c)
+    w[prefix + "f0_predictor.classifier.weight"] = (rng.standard_normal((1, c), dtype=F32) * F32(160.0 / np.sqrt(c))).astype(F32)
+    w[prefix + "f0_predictor.classifier.bias"] = np.array([25.0], dtype=F32)       # f0 around 0..200 Hz: voiced and unvoiced frames
+    w[prefix + "m_source.l_linear.weight"] = (rng.standard_normal((1, dims.n_harm), dtype=F32) * F32(2.0)).astype(F32)
+    w[prefix + "m_source.l_linear.bias"] = np.array([0.01], dtype=F32)
+    pconv("conv_pre", dims.base, dims.mel, 7)
+    bias("conv_pre", dims.base)
+
+    def resblock(p, ch, k):
+        for j in range(3):
+            pconv(f"{p}.convs1.{j}", ch, ch, k, gain=0.5)
+            bias(f"{p}.convs1.{j}", ch)
+            pconv(f"{p}.convs2.{j}", ch, ch, k, gain=0.5)
+            bias(f"{p}.convs2.{j}", ch)
+            w[prefix + f"{p}.activations1.{j}.alpha"] = (F32(1) + F32(0.3) * rng.standard_normal(ch, dtype=F32)).astype(F32)
+            w[prefix + f"{p}.activations2.{j}.alpha"] = (F32(1) + F32(0.3) * rng.standard_normal(ch, dtype=F32)).astype(F32)
+
+    total = int(np.prod([u for u, _ in HIFT_UPS]))
+    cum = 1
+    for i, (u, k) in enumerate(HIFT_UPS):
+        cin, cout = dims.base >> i, dims.base >> (i + 1)
+        pconv(f"ups.{i}", cin, cout, k, gain=1.5)          # conv-transpose layout [in, out, k]
+        bias(f"ups.{i}", cout)
+        cum *= u
+        du = total // cum
+        kd = 1 if du == 1 else 2 * du
+        w[prefix + f"source_downs.{i}.weight"] = (rng.standard_normal((cout, dims.n_fft + 2, kd), dtype=F32) *
+                                                  F32(0.5 / np.sqrt((dims.n_fft + 2) * kd))).astype(F32)
+        bias(f"source_downs.{i}", cout)
+        resblock(f"source_resblocks.{i}", cout, HIFT_SRC_K[i])
+        for j, rk in enumerate(HIFT_RES_K):
+            resblock(f"resblocks.{i * 3 + j}", cout, rk)
+    pconv("conv_post", dims.n_fft + 2, dims.base >> 3, 7, gain=0.6)
+    bias("conv_post", dims.n_fft + 2)
+    return w
+
+
+def ensure_hift_checkpoint(dims: HiftDims = HIFT_FULL, seed: int = 999, root: str | None = None) -> str:
+    root = root or os.environ.get("T3MI_SYNTH_DIR", "/tmp/t3mi_synth")
+    os.makedirs(root, exist_ok=True)
+    path = os.path.join(root, f"s3gen_hift_b{dims.base}_f{dims.f0_ch}_mel{dims.mel}_s{seed}.safetensors")
+    if not os.path.exists(path):
+        write_safetensors(synth_hift_weights(dims, seed), path)
+    return path
+
+
+def synth_hift_inputs(dims: HiftDims, T: int, seed: int):
+    """mel [mel, T], harmonic start phases [n_harm] in (-pi, pi), source noise [n_harm, T * 480] (standard normal)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mel = rng.standard_normal((dims.mel, T), dtype=F32)
+    phase = rng.uniform(-np.pi, np.pi, dims.n_harm).astype(F32)
+    noise = rng.standard_normal((dims.n_harm, T * 480), dtype=F32)
+    return mel, phase, noise

@@ -291,6 +291,30 @@ int t3mi_flow_inference(t3mi_cfm* m, const int32_t* token, int n_token, const in
                         int n_timesteps, double cfg_rate, int meanflow, int finalize, float* out, int cap_frames, int* n_frames,
                         float* device_ms);
 
+/* ---- HiFT vocoder: mel -> waveform (third piece) ----------------------------------------------------------
+ * hift_generator as create_s3gen_vocoder configures it (R/hifigan.R:337-627, 788-817): F0 predictor, harmonic-plus-noise
+ * source (9 harmonics at 24 kHz), ISTFTNet decoder (upsampling 8 x 5 x 3, residual blocks with Snake activations, 16-point
+ * inverse STFT, hop 4): 480 samples per mel frame.  One utterance per call. */
+typedef struct t3mi_hift t3mi_hift;
+typedef struct t3mi_hift_info {
+    int32_t mel, base_channels, f0_channels, n_harmonics, samples_per_frame, sampling_rate, device, reserved_;
+    int64_t weight_bytes;
+} t3mi_hift_info;
+/* create_s3gen_vocoder + load_hifigan_weights (R/hifigan.R:640-817) from the unchanged s3gen safetensors file, keys under
+ * `prefix` (NULL = "mel2wav."): weight-normalised convolutions arrive as parametrizations.weight.original0 / original1 pairs and
+ * are folded at load (w = g v / ||v||, :649-667). */
+int t3mi_hift_open(const char* safetensors_path, const char* prefix, int device, t3mi_hift** out);
+int t3mi_hift_close(t3mi_hift* m);
+int t3mi_hift_get_info(const t3mi_hift* m, t3mi_hift_info* info);
+/* hift_generator$inference(speech_feat) without a source cache (R/hifigan.R:601-626): mel (80, T) -> audio [480 T], clamped
+ * to +-0.99 (:577).  The reference draws the harmonics' start phases (uniform(-pi, pi), entry 0 forced to 0) and the source
+ * noise (standard normal, [n_harmonics][480 T]) from torch's generator (:237-249): here the caller hands them in (phase NULL:
+ * zeros; noise NULL: no noise term).  source_out [480 T] and f0_out [T] (either may be NULL) return the source signal and the
+ * predicted F0 (the list elements `source` / `f0` of the reference's result).  s3gen$inference then applies its 20 ms fade-in
+ * (R/s3gen.R:1047-1049), which stays with the caller.  device_ms (may be NULL): HIP-event time of the pass. */
+int t3mi_hift_inference(t3mi_hift* m, int T, const float* mel, const float* phase, const float* noise, float* audio, float* source_out,
+                        float* f0_out, float* device_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -402,3 +402,188 @@ def flow_inference(weights, token, prompt_token, prompt_feat, embedding, noise, 
     z = np.asarray(noise, dtype=F32)[:, :, :T]
     feat = basic_euler(est, z, mu, mask, spks, cond, n_timesteps) if meanflow else solve_euler(est, z, mu, mask, spks, cond, n_timesteps)
     return feat[:, :, mel_len1:].copy()                                                                      # :887
+
+
+# =====================================================================================================================
+# HiFT vocoder (R/hifigan.R:13-627): F0 predictor -> harmonic-plus-noise source -> ISTFTNet decoder.  Same status as above:
+# pinned op-for-op against CPU libtorch (conv1d, conv_transpose1d, stft, istft, cumsum ...), PARITY UNPINNED against the
+# reference itself.  One utterance (B = 1).  The reference draws the harmonics' start phases and the source noise from
+# torch's generator (R/hifigan.R:237-249); here the caller hands them in.
+# =====================================================================================================================
+
+def conv1d_full(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], stride: int = 1, padding: int = 0, dilation: int = 1) -> np.ndarray:
+    """nn_conv1d on one sequence: x [Cin, L], w [Cout, Cin, k] -> [Cout, Lout]."""
+    Cin, L = x.shape
+    k = w.shape[2]
+    xp = np.concatenate([np.zeros((Cin, padding), F32), x.astype(F32), np.zeros((Cin, padding), F32)], axis=1)
+    Lout = (L + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+    y = np.zeros((w.shape[0], Lout), F32)
+    for j in range(k):
+        seg = xp[:, j * dilation: j * dilation + (Lout - 1) * stride + 1: stride]
+        y += (w[:, :, j].astype(F32) @ seg).astype(F32)
+    if b is not None:
+        y = y + b.astype(F32)[:, None]
+    return y.astype(F32)
+
+
+def conv_transpose1d(x: np.ndarray, w: np.ndarray, b: np.ndarray, stride: int, padding: int, output_padding: int = 0) -> np.ndarray:
+    """nn_conv_transpose1d on one sequence: x [Cin, L], w [Cin, Cout, k] -> [Cout, (L - 1) stride - 2 padding + k + output_padding]."""
+    Cin, L = x.shape
+    k = w.shape[2]
+    full = np.zeros((w.shape[1], (L - 1) * stride + k + output_padding), F32)
+    for j in range(k):
+        full[:, j: j + (L - 1) * stride + 1: stride] += (w[:, :, j].astype(F32).T @ x.astype(F32)).astype(F32)
+    out = full[:, padding: full.shape[1] - padding]
+    return (out + b.astype(F32)[:, None]).astype(F32)
+
+
+def weight_norm_weight(g: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """get_parametrized_weight (R/hifigan.R:649-667): w = g * v / ||v||, the norm over all but the first axis."""
+    nrm = np.sqrt((v.reshape(v.shape[0], -1).astype(F32) ** 2).sum(axis=1, dtype=F32), dtype=F32).reshape(-1, 1, 1)
+    return (g.astype(F32) * v.astype(F32) / nrm).astype(F32)
+
+
+def snake(x: np.ndarray, alpha: np.ndarray) -> np.ndarray:
+    """snake_activation (R/hifigan.R:75-86), alpha_logscale = FALSE: x + 1 / (a + 1e-9) * sin(x a)^2, per channel."""
+    a = alpha.astype(F32)[:, None]
+    return (x + (F32(1.0) / (a + F32(1e-9))) * np.sin(x * a, dtype=F32) ** 2).astype(F32)
+
+
+def elu(x):
+    return np.where(x > 0, x, np.expm1(np.minimum(x, F32(0)), dtype=F32)).astype(F32)
+
+
+def leaky_relu(x, slope):
+    return np.where(x >= 0, x, x * F32(slope)).astype(F32)
+
+
+HIFT_UPS = ((8, 16), (5, 11), (3, 7))          # create_s3gen_vocoder (R/hifigan.R:804-805): (rate, kernel)
+HIFT_RES_K = (3, 7, 11)
+HIFT_SRC_K = (7, 7, 11)
+HIFT_DIL = (1, 3, 5)
+
+
+class HiftOracle:
+    """hift_generator (R/hifigan.R:337-627) as create_s3gen_vocoder configures it (:788-817), weights through
+    load_hifigan_weights' key map (:640-777) with the weight-norm pairs already folded."""
+
+    def __init__(self, weights: Dict[str, np.ndarray], prefix: str = "mel2wav.", sampling_rate: int = 24000, n_fft: int = 16, hop: int = 4,
+                 ups=HIFT_UPS):
+        raw = {k[len(prefix):]: np.asarray(v, dtype=F32) for k, v in weights.items() if k.startswith(prefix)}
+        w: Dict[str, np.ndarray] = {}
+        for k, v in raw.items():
+            if k.endswith(".parametrizations.weight.original0"):
+                base = k[: -len(".parametrizations.weight.original0")]
+                w[base + ".weight"] = weight_norm_weight(v, raw[base + ".parametrizations.weight.original1"])
+            elif not k.endswith(".parametrizations.weight.original1"):
+                w[k] = v
+        self.w, self.sr, self.n_fft, self.hop, self.ups = w, sampling_rate, n_fft, hop, tuple(ups)
+        self.total_up = int(np.prod([u for u, _ in ups])) * hop
+        self.n_harm = w["m_source.l_linear.weight"].shape[1]          # harmonic_num + 1
+        n = np.arange(n_fft, dtype=np.float64)
+        self.window = (0.5 * (1 - np.cos(2 * np.pi * n / n_fft))).astype(F32)      # R/hifigan.R:458-461
+
+    def f0_predictor(self, mel: np.ndarray) -> np.ndarray:
+        """conv_rnn_f0_predictor (R/hifigan.R:174-180): mel [80, T] -> f0 [T]."""
+        x = mel.astype(F32)
+        for i in range(5):
+            x = elu(conv1d_full(x, self.w[f"f0_predictor.condnet.{2 * i}.weight"], self.w[f"f0_predictor.condnet.{2 * i}.bias"], padding=1))
+        y = _lin(x.T, self.w["f0_predictor.classifier.weight"], self.w["f0_predictor.classifier.bias"])[:, 0]
+        return np.abs(y).astype(F32)
+
+    def source(self, f0: np.ndarray, phase: np.ndarray, noise: np.ndarray) -> np.ndarray:
+        """f0_upsamp + source_module_hn_nsf (R/hifigan.R:216-256, 291-307, 609-614): f0 [T] -> sine_merge [T * total_up].
+        phase [n_harm] (entry 0 forced to 0), noise [n_harm, T_wav] standard normal."""
+        up = np.repeat(f0.astype(F32), self.total_up)                                         # nn_upsample, nearest
+        h = np.arange(1, self.n_harm + 1, dtype=F32)
+        fmat = ((up[None, :] * h[:, None]).astype(F32) / F32(self.sr)).astype(F32)            # :230
+        cs = np.cumsum(fmat.astype(np.float64), axis=1).astype(F32)                           # libtorch CPU cumsum: double accumulate
+        theta = (F32(2 * math.pi) * np.mod(cs, F32(1))).astype(F32)                           # :234
+        ph = phase.astype(F32).copy()
+        ph[0] = 0
+        sine = (F32(0.1) * np.sin(theta + ph[:, None], dtype=F32)).astype(F32)                # :242
+        uv = (up > F32(10)).astype(F32)[None, :]                                              # voiced_threshold 10 (:803)
+        namp = (uv * F32(0.003) + (F32(1) - uv) * F32(0.1) / F32(3)).astype(F32)              # :248
+        sine = (sine * uv + namp * noise.astype(F32)).astype(F32)                             # :249-252
+        lin = _lin(sine.T, self.w["m_source.l_linear.weight"], self.w["m_source.l_linear.bias"])[:, 0]
+        return np.tanh(lin, dtype=F32)                                                        # :301
+
+    def stft(self, s: np.ndarray) -> np.ndarray:
+        """torch_stft(center = TRUE, reflect, hann, onesided) then cat(real, imag) (R/hifigan.R:464-481, 516-517): [n_fft + 2, frames]."""
+        n, hop = self.n_fft, self.hop
+        sp = np.pad(s.astype(F32), (n // 2, n // 2), mode="reflect")
+        frames = 1 + (sp.size - n) // hop
+        idx = np.arange(n)[None, :] + hop * np.arange(frames)[:, None]
+        seg = (sp[idx] * self.window[None, :]).astype(F32)
+        spec = np.fft.rfft(seg.astype(np.float64), axis=1)
+        return np.concatenate([spec.real.T, spec.imag.T], axis=0).astype(F32)
+
+    def istft(self, mag: np.ndarray, phase: np.ndarray) -> np.ndarray:
+        """.istft (R/hifigan.R:483-501): clamp, polar -> complex, torch_istft(center = TRUE): windowed overlap-add over the
+        window envelope, n_fft / 2 trimmed from both ends."""
+        n, hop = self.n_fft, self.hop
+        mag = np.minimum(mag.astype(F32), F32(100))
+        re, im = (mag * np.cos(phase, dtype=F32)).astype(F32), (mag * np.sin(phase, dtype=F32)).astype(F32)
+        frames = re.shape[1]
+        seg = np.fft.irfft((re.astype(np.float64) + 1j * im.astype(np.float64)).T, n=n, axis=1).astype(F32)
+        seg = (seg * self.window[None, :]).astype(F32)
+        L = n + hop * (frames - 1)
+        y = np.zeros(L, np.float64)
+        env = np.zeros(L, np.float64)
+        w2 = (self.window.astype(np.float64)) ** 2
+        for f in range(frames):
+            y[f * hop: f * hop + n] += seg[f]
+            env[f * hop: f * hop + n] += w2
+        y, env = y[n // 2: L - n // 2], env[n // 2: L - n // 2]
+        return (y / env).astype(F32)
+
+    def resblock(self, x, p, k):
+        """hifigan_resblock$forward (R/hifigan.R:129-139)."""
+        w = self.w
+        for j, d in enumerate(HIFT_DIL):
+            xt = snake(x, w[f"{p}.activations1.{j}.alpha"])
+            xt = conv1d_full(xt, w[f"{p}.convs1.{j}.weight"], w[f"{p}.convs1.{j}.bias"], padding=(k * d - d) // 2, dilation=d)
+            xt = snake(xt, w[f"{p}.activations2.{j}.alpha"])
+            xt = conv1d_full(xt, w[f"{p}.convs2.{j}.weight"], w[f"{p}.convs2.{j}.bias"], padding=(k - 1) // 2)
+            x = (xt + x).astype(F32)
+        return x
+
+    def decode(self, mel: np.ndarray, s: np.ndarray) -> np.ndarray:
+        """hift_generator$decode (R/hifigan.R:503-578): mel [80, T], source s [T_wav] -> audio [T_wav]."""
+        w = self.w
+        s_stft = self.stft(s)
+        x = conv1d_full(mel.astype(F32), w["conv_pre.weight"], w["conv_pre.bias"], padding=3)
+        rates = [u for u, _ in self.ups]
+        total = int(np.prod(rates))
+        cum = np.cumprod(rates)
+        for i, (u, k) in enumerate(self.ups):
+            x = leaky_relu(x, 0.1)
+            x = conv_transpose1d(x, w[f"ups.{i}.weight"], w[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
+            if i == len(self.ups) - 1:
+                x = np.concatenate([x[:, 1:2], x], axis=1)                                   # reflection_pad1d(c(1, 0)), :455, :533
+            du = total // int(cum[i])
+            if du == 1:
+                si = conv1d_full(s_stft, w[f"source_downs.{i}.weight"], w[f"source_downs.{i}.bias"])
+            else:
+                si = conv1d_full(s_stft, w[f"source_downs.{i}.weight"], w[f"source_downs.{i}.bias"], stride=du, padding=du // 2)
+            si = self.resblock(si, f"source_resblocks.{i}", HIFT_SRC_K[i])
+            L = min(x.shape[1], si.shape[1])
+            x = (x[:, :L] + si[:, :L]).astype(F32)
+            xs = None
+            for j, rk in enumerate(HIFT_RES_K):
+                r = self.resblock(x, f"resblocks.{i * len(HIFT_RES_K) + j}", rk)
+                xs = r if xs is None else (xs + r).astype(F32)
+            x = (xs / F32(len(HIFT_RES_K))).astype(F32)
+        x = leaky_relu(x, 0.01)                                                               # nnf_leaky_relu default slope, :565
+        x = conv1d_full(x, w["conv_post.weight"], w["conv_post.bias"], padding=3)
+        nf = self.n_fft // 2 + 1
+        mag = np.exp(x[:nf], dtype=F32)
+        ph = np.sin(x[nf:], dtype=F32)                                                        # :571
+        audio = self.istft(mag, ph)
+        return np.clip(audio, F32(-0.99), F32(0.99)).astype(F32)
+
+    def inference(self, mel: np.ndarray, phase: np.ndarray, noise: np.ndarray):
+        """hift_generator$inference (R/hifigan.R:601-626) without a source cache: mel [80, T] -> (audio [T * 480], source)."""
+        f0 = self.f0_predictor(mel)
+        s = self.source(f0, phase, noise)
+        return self.decode(mel, s), s

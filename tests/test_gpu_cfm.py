@@ -192,3 +192,86 @@ def test_flow_rejects_bad_input():
     with cb.load_cfm_estimator(synth.ensure_cfm_checkpoint(synth.CFM_TINY, 777)) as est:
         rc = est._lib.t3mi_flow_encoder(est._h, 4, None, None)
         assert rc == _lib.ERR_STATE
+
+
+# ---- HiFT vocoder: mel -> waveform (R/hifigan.R) -----------------------------------------------------------------------
+
+def _hift_check(dims, T, seed, wseed=999):
+    w = synth.synth_hift_weights(dims, wseed)
+    mel, phase, noise = synth.synth_hift_inputs(dims, T, seed)
+    orc = S.HiftOracle(w)
+    tm = {}
+    with cb.load_hift_vocoder(synth.ensure_hift_checkpoint(dims, wseed)) as voc:
+        assert (voc.info.mel, voc.info.base_channels, voc.info.n_harmonics, voc.info.samples_per_frame, voc.info.sampling_rate) == \
+            (dims.mel, dims.base, dims.n_harm, 480, 24000)
+        got = voc.inference(mel[None], phase, noise, timing=tm)
+        again = voc.inference(mel, phase, noise)
+    f0 = orc.f0_predictor(mel)
+    assert _rel(got["f0"], f0) < 1e-4
+    assert (f0 > 10).any() and (f0 <= 10).any()
+    # the source integrates F0 over thousands of samples (a phase in float32, as in the reference): compared on the GPU's own
+    # F0 so that its 1e-6 relative difference does not decide the test; the decoder likewise on the GPU's own source
+    src = orc.source(got["f0"], phase, noise)
+    assert np.abs(got["source"] - src).max() < 2e-3, np.abs(got["source"] - src).max()
+    audio = orc.decode(mel, got["source"])
+    assert got["audio"].shape == (T * 480,) and np.isfinite(got["audio"]).all() and tm["device_ms"] > 0
+    err = np.abs(got["audio"] - audio).max()
+    assert err < TOL * max(1.0, np.abs(audio).max()), err
+    assert np.abs(audio).mean() > 0.01 and (np.abs(audio) < 0.99).mean() > 0.5
+    assert np.array_equal(got["audio"], again["audio"])
+    return err
+
+
+@pytest.mark.parametrize("T", [7, 50])
+def test_hift_vocoder_matches_the_oracle_tiny(T):
+    """hift_generator$inference on a reduced vocoder (64 base channels): F0 predictor, source, STFT, three upsampling stages with
+    source fusion and averaged residual blocks, conv_post, inverse STFT, clamp."""
+    _hift_check(synth.HIFT_TINY, T, 6)
+
+
+def test_hift_vocoder_matches_the_oracle_full_size():
+    """The real vocoder (80 mel bins, 512 base channels, 9 + 3 residual blocks) on 30 frames = 0.6 s of audio."""
+    _hift_check(synth.HIFT_FULL, 30, 8)
+
+
+def test_hift_without_noise_or_phase_and_bad_input():
+    dims = synth.HIFT_TINY
+    w = synth.synth_hift_weights(dims, 999)
+    mel, phase, noise = synth.synth_hift_inputs(dims, 9, 2)
+    orc = S.HiftOracle(w)
+    with cb.load_hift_vocoder(synth.ensure_hift_checkpoint(dims, 999)) as voc:
+        got = voc.inference(mel)                       # no phases, no noise term
+        src = orc.source(got["f0"], np.zeros(dims.n_harm, np.float32), np.zeros((dims.n_harm, 9 * 480), np.float32))
+        assert np.abs(got["source"] - src).max() < 2e-3
+        with pytest.raises(_lib.T3miError) as e:
+            voc.inference(mel[:, :1])
+        assert e.value.code == _lib.ERR_ARG
+    with pytest.raises(_lib.T3miError) as e:
+        cb.load_hift_vocoder(synth.ensure_cfm_checkpoint(synth.CFM_TINY, 777))
+    assert e.value.code == _lib.ERR_IO
+
+
+def test_s3gen_inference_tokens_to_waveform():
+    """s3gen$inference end to end (R/s3gen.R:987-1056) on reduced modules that share the mel width: speech tokens + the voice's
+    ref_dict -> flow (conformer encoder + 10-step CFM) -> HiFT -> 20 ms silence + 20 ms fade-in; the mel against the oracle's
+    flow, the waveform against the oracle's vocoder on that mel's own source."""
+    fd, hd = synth.FLOW_TINY, synth.HIFT_TINY
+    assert fd.cfm.mel == hd.mel
+    wf, wh = synth.synth_flow_weights(fd, 555), synth.synth_hift_weights(hd, 999)
+    tok, ptok, pfeat, xvec, z = synth.synth_flow_inputs(fd, 12, 7, 4)
+    rng = np.random.default_rng(1)
+    phase = rng.uniform(-np.pi, np.pi, hd.n_harm).astype(np.float32)
+    snoise = rng.standard_normal((hd.n_harm, 24 * 480)).astype(np.float32)
+    want_mel = S.flow_inference(wf, tok, ptok, pfeat, xvec, z, n_timesteps=10, heads=fd.heads, cfm_heads=fd.cfm.heads)
+    tm = {}
+    with cb.load_s3gen_flow(synth.ensure_flow_checkpoint(fd, 555)) as flow, cb.load_hift_vocoder(synth.ensure_hift_checkpoint(hd, 999)) as voc:
+        audio, mel = cb.s3gen_inference(flow, voc, tok, dict(prompt_token=ptok, prompt_feat=pfeat, embedding=xvec), z, phase, snoise, timing=tm)
+        raw = voc.inference(mel, phase, snoise)
+    assert mel.shape == (1, hd.mel, 24) and audio.shape == (24 * 480,)
+    assert _rel(mel, want_mel) < TOL
+    assert not audio[:480].any() and np.array_equal(audio[960:], raw["audio"][960:])
+    ref_audio = S.HiftOracle(wh).decode(mel[0], raw["source"])
+    ramp = (np.cos(np.linspace(np.pi, 0, 480)) + 1) / 2
+    assert np.abs(audio[480:960] - ref_audio[480:960] * ramp).max() < TOL
+    assert np.abs(audio[960:] - ref_audio[960:]).max() < TOL
+    assert tm["flow_ms"] > 0 and tm["vocoder_ms"] > 0

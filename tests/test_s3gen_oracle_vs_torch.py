@@ -264,3 +264,118 @@ def test_flow_inputs_and_inference_shapes():
     assert np.abs(spks - want).max() < 1e-6
     out = S.flow_inference(w, tok, ptok, pfeat, xvec, z, n_timesteps=3, heads=dims.heads, cfm_heads=dims.cfm.heads)
     assert out.shape == (1, dims.cfm.mel, 18) and np.isfinite(out).all()
+
+
+# ---- HiFT vocoder (R/hifigan.R) ---------------------------------------------------------------------------------------
+
+class TorchHift:
+    """hift_generator$inference with the ATen calls of R/hifigan.R, weights through load_hifigan_weights' weight-norm fold."""
+
+    def __init__(self, w, prefix="mel2wav."):
+        raw = {k[len(prefix):]: torch.from_numpy(v) for k, v in w.items() if k.startswith(prefix)}
+        self.w = {}
+        for k, v in raw.items():
+            if k.endswith(".parametrizations.weight.original0"):
+                base = k[: -len(".parametrizations.weight.original0")]
+                vv = raw[base + ".parametrizations.weight.original1"]
+                nrm = vv.reshape(vv.shape[0], -1).norm(dim=1, keepdim=True).unsqueeze(2)
+                self.w[base + ".weight"] = v * vv / nrm
+            elif not k.endswith(".parametrizations.weight.original1"):
+                self.w[k] = v
+        self.window = torch.tensor(0.5 * (1 - np.cos(2 * np.pi * np.arange(16) / 16)), dtype=torch.float32)
+
+    def snake(self, x, a):
+        a = a.unsqueeze(0).unsqueeze(2)
+        return x + (1.0 / (a + 1e-9)) * torch.pow(torch.sin(x * a), 2)
+
+    def resblock(self, x, p, k):
+        for j, d in enumerate((1, 3, 5)):
+            xt = self.snake(x, self.w[f"{p}.activations1.{j}.alpha"])
+            xt = F.conv1d(xt, self.w[f"{p}.convs1.{j}.weight"], self.w[f"{p}.convs1.{j}.bias"], dilation=d, padding=(k * d - d) // 2)
+            xt = self.snake(xt, self.w[f"{p}.activations2.{j}.alpha"])
+            xt = F.conv1d(xt, self.w[f"{p}.convs2.{j}.weight"], self.w[f"{p}.convs2.{j}.bias"], padding=(k - 1) // 2)
+            x = xt + x
+        return x
+
+    def f0(self, mel):
+        x = mel
+        for i in range(5):
+            x = F.elu(F.conv1d(x, self.w[f"f0_predictor.condnet.{2 * i}.weight"], self.w[f"f0_predictor.condnet.{2 * i}.bias"], padding=1))
+        return torch.abs(F.linear(x.transpose(1, 2), self.w["f0_predictor.classifier.weight"], self.w["f0_predictor.classifier.bias"]).squeeze(2))
+
+    def source(self, f0, phase, noise):
+        s = F.interpolate(f0.unsqueeze(1), scale_factor=480.0, mode="nearest")            # (1, 1, T_wav)
+        nh = self.w["m_source.l_linear.weight"].shape[1]
+        fm = torch.zeros(1, nh, s.shape[2])
+        for i in range(nh):
+            fm[:, i, :] = s.squeeze(1) * (i + 1) / 24000
+        theta = 2 * np.pi * (torch.cumsum(fm, dim=2) % 1)
+        ph = phase.clone().view(1, nh, 1)
+        ph[:, 0, :] = 0
+        sine = 0.1 * torch.sin(theta + ph)
+        uv = (s > 10).to(torch.float32)
+        namp = uv * 0.003 + (1 - uv) * 0.1 / 3
+        sine = sine * uv + namp * noise.unsqueeze(0)
+        return torch.tanh(F.linear(sine.transpose(1, 2), self.w["m_source.l_linear.weight"], self.w["m_source.l_linear.bias"])).transpose(1, 2)
+
+    def decode(self, mel, s):
+        w = self.w
+        spec = torch.stft(s.squeeze(1), n_fft=16, hop_length=4, win_length=16, window=self.window, return_complex=True)
+        s_stft = torch.cat([spec.real, spec.imag], dim=1)
+        x = F.conv1d(mel, w["conv_pre.weight"], w["conv_pre.bias"], padding=3)
+        ups, total, cum = ((8, 16), (5, 11), (3, 7)), 120, 1
+        for i, (u, k) in enumerate(ups):
+            x = F.conv_transpose1d(F.leaky_relu(x, 0.1), w[f"ups.{i}.weight"], w[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
+            if i == 2:
+                x = F.pad(x, (1, 0), mode="reflect")
+            cum *= u
+            du = total // cum
+            si = F.conv1d(s_stft, w[f"source_downs.{i}.weight"], w[f"source_downs.{i}.bias"], stride=du, padding=0 if du == 1 else du // 2)
+            si = self.resblock(si, f"source_resblocks.{i}", (7, 7, 11)[i])
+            L = min(x.shape[2], si.shape[2])
+            x = x[:, :, :L] + si[:, :, :L]
+            xs = sum(self.resblock(x, f"resblocks.{i * 3 + j}", rk) for j, rk in enumerate((3, 7, 11)))
+            x = xs / 3
+        x = F.conv1d(F.leaky_relu(x), w["conv_post.weight"], w["conv_post.bias"], padding=3)
+        mag, ph = torch.clamp(torch.exp(x[:, :9]), max=100), torch.sin(x[:, 9:])
+        audio = torch.istft(torch.complex(mag * torch.cos(ph), mag * torch.sin(ph)), n_fft=16, hop_length=4, win_length=16, window=self.window)
+        return torch.clamp(audio, -0.99, 0.99)
+
+
+def test_hift_vocoder_matches_libtorch():
+    dims = synth.HIFT_TINY
+    w = synth.synth_hift_weights(dims, 999)
+    T = 11
+    mel, phase, noise = synth.synth_hift_inputs(dims, T, 6)
+    orc = S.HiftOracle(w)
+    th = TorchHift(w)
+    with torch.no_grad():
+        tm = torch.from_numpy(mel)[None]
+        f0_t = th.f0(tm)
+        s_t = th.source(f0_t, torch.from_numpy(phase), torch.from_numpy(noise))
+        a_t = th.decode(tm, s_t)[0].numpy()
+    f0 = orc.f0_predictor(mel)
+    assert np.abs(f0 - f0_t[0].numpy()).max() < 2e-4 * max(1.0, np.abs(f0).max())
+    assert (f0 > 10).any() and (f0 <= 10).any()              # voiced and unvoiced frames both occur
+    # the source on libtorch's own f0 (the phase accumulates f0 over thousands of samples: a 1e-5 relative difference in f0
+    # would dominate the comparison of everything behind it)
+    s = orc.source(f0_t[0].numpy(), phase, noise)
+    assert s.shape == (T * 480,) and np.abs(s - s_t[0, 0].numpy()).max() < 2e-4
+    stft = orc.stft(s_t[0, 0].numpy())
+    with torch.no_grad():
+        sp = torch.stft(s_t[0], n_fft=16, hop_length=4, win_length=16, window=th.window, return_complex=True)[0]
+    assert stft.shape == (18, T * 120 + 1)
+    assert np.abs(stft - torch.cat([sp.real, sp.imag], dim=0).numpy()).max() < 1e-5
+    audio = orc.decode(mel, s_t[0, 0].numpy())
+    assert audio.shape == (T * 480,) and np.isfinite(audio).all()
+    assert np.abs(audio - a_t).max() < 2e-4, np.abs(audio - a_t).max()
+    assert 0.01 < np.abs(audio).mean() and (np.abs(audio) < 0.99).mean() > 0.5     # neither silent nor pinned at the clip
+
+
+def test_istft_inverts_stft_of_the_oracle():
+    orc = S.HiftOracle(synth.synth_hift_weights(synth.HIFT_TINY, 999))
+    x = np.random.default_rng(0).standard_normal(480).astype(np.float32)
+    st = orc.stft(x)
+    re, im = st[:9], st[9:]
+    back = orc.istft(np.hypot(re, im), np.arctan2(im, re))
+    assert np.abs(back - x).max() < 1e-4
