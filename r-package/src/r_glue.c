@@ -279,12 +279,22 @@ SEXP t3mi_r_generate_tokens(SEXP model, SEXP conds, SEXP texts, SEXP cfg) {
 
 #endif /* HAVE_T3MI */
 
+/* S3Gen entry points (r_glue_s3gen.c) */
+SEXP t3mi_r_flow_open(SEXP, SEXP);
+SEXP t3mi_r_hift_open(SEXP, SEXP);
+SEXP t3mi_r_flow_inference(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
+SEXP t3mi_r_hift_inference(SEXP, SEXP, SEXP, SEXP, SEXP);
+
 static const R_CallMethodDef call_methods[] = {
     {"t3mi_r_open", (DL_FUNC)&t3mi_r_open, 5},
     {"t3mi_r_close", (DL_FUNC)&t3mi_r_close, 1},
     {"t3mi_r_generate", (DL_FUNC)&t3mi_r_generate, 4},
     {"t3mi_r_generate_batch", (DL_FUNC)&t3mi_r_generate_batch, 4},
     {"t3mi_r_generate_tokens", (DL_FUNC)&t3mi_r_generate_tokens, 4},
+    {"t3mi_r_flow_open", (DL_FUNC)&t3mi_r_flow_open, 2},
+    {"t3mi_r_hift_open", (DL_FUNC)&t3mi_r_hift_open, 2},
+    {"t3mi_r_flow_inference", (DL_FUNC)&t3mi_r_flow_inference, 7},
+    {"t3mi_r_hift_inference", (DL_FUNC)&t3mi_r_hift_inference, 5},
     {NULL, NULL, 0}};
 
 /* same registration pattern as the reference's src/init.c:12-15 */

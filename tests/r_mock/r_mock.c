@@ -259,3 +259,45 @@ int mock_generate_batch(int n_utt, const float* const* embeds_row_major, int row
     const int rc = copy_list_out(res, n_utt, out, cap, n_out);
     LEAVE(rc);
 }
+
+/* ---- S3Gen (r_glue_s3gen.c): open both handles, tokens -> mel -> waveform through the four .Call entry points; the handles
+ * live in the per-call arena, so their finalizers (run by free_all, as R's GC would) close them on every path. ---- */
+typedef SEXP (*call2)(SEXP, SEXP);
+typedef SEXP (*call7)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
+static SEXP mk_real_f(const float* v, R_xlen_t n) { SEXP s = Rf_allocVector(REALSXP, n); for (R_xlen_t i = 0; i < n; i++) REAL(s)[i] = v[i]; return s; }
+
+/* bad: 0 none, 1 token ids as doubles, 2 prompt_feat one value short, 3 token id outside the vocabulary, 4 mel one value short */
+int mock_s3gen(const char* flow_path, const char* hift_path, const int32_t* tok, int n_tok, const int32_t* ptok, int n_ptok,
+               const float* pfeat, int n_feat, int mel_bins, const float* emb, int n_emb, const float* noise, int noise_T, int steps,
+               double cfg_rate, int meanflow, int finalize, const float* phase, int n_harm, const float* src_noise, int bad,
+               float* mel_out, int cap_frames, int32_t* n_frames, float* audio_out) {
+    ENTER();
+    call2 fopen_ = (call2)find_call("t3mi_r_flow_open", 2), hopen = (call2)find_call("t3mi_r_hift_open", 2);
+    call7 finf = (call7)find_call("t3mi_r_flow_inference", 7);
+    call5 hinf = (call5)find_call("t3mi_r_hift_inference", 5);
+    if (!fopen_ || !hopen || !finf || !hinf) { snprintf(g_error, sizeof(g_error), "S3Gen routines not registered"); LEAVE(-2); }
+    SEXP flow = fopen_(mk_str1(flow_path), mk_int1(0));
+    SEXP voc = hopen(mk_str1(hift_path), mk_int1(0));
+    SEXP cfg = Rf_allocVector(REALSXP, 6);
+    const double c[6] = {(double)steps, cfg_rate, (double)meanflow, (double)finalize, (double)n_feat, (double)noise_T};
+    for (int i = 0; i < 6; i++) REAL(cfg)[i] = c[i];
+    SEXP tk;
+    if (bad == 1) tk = Rf_allocVector(REALSXP, n_tok);
+    else {
+        tk = mk_int(tok, n_tok);
+        if (bad == 3) INTEGER(tk)[0] = 1 << 20;
+    }
+    SEXP mel = finf(flow, tk, mk_int(ptok, n_ptok), mk_real_f(pfeat, (R_xlen_t)n_feat * mel_bins - (bad == 2)), mk_real_f(emb, n_emb),
+                    mk_real_f(noise, (R_xlen_t)noise_T * mel_bins), cfg);
+    if (TYPEOF(mel) != REALSXP || Rf_xlength(mel) % mel_bins || Rf_xlength(mel) / mel_bins > cap_frames) LEAVE(-5);
+    const int T = (int)(Rf_xlength(mel) / mel_bins);
+    *n_frames = T;
+    for (R_xlen_t i = 0; i < Rf_xlength(mel); i++) mel_out[i] = (float)REAL(mel)[i];
+    SEXP mel_in = mel;
+    if (bad == 4) mel_in = Rf_allocVector(REALSXP, Rf_xlength(mel) - 1);
+    SEXP wav = hinf(voc, mel_in, mk_int1(T), phase ? mk_real_f(phase, n_harm) : R_NilValue,
+                    src_noise ? mk_real_f(src_noise, (R_xlen_t)n_harm * 480 * T) : R_NilValue);
+    if (TYPEOF(wav) != REALSXP || Rf_xlength(wav) != (R_xlen_t)480 * T) LEAVE(-6);
+    for (R_xlen_t i = 0; i < Rf_xlength(wav); i++) audio_out[i] = (float)REAL(wav)[i];
+    LEAVE(0);
+}

@@ -142,3 +142,61 @@ def test_text_ids_of_the_wrong_r_type_are_refused(glue):
     conds = [((rng.standard_normal(dims.speaker_embed) * 0.1).astype(np.float32), rng.integers(0, dims.start_speech_token, 10), 0.5)]
     rc, _ = _tokens_call(lib, dims, conds, [rng.integers(1, 250, 5)], _cfg(dims), wrong_types=1)
     assert rc == -1 and b"text_tokens integer" in lib.mock_last_error()
+
+
+# ---- S3Gen through the glue (r-package/src/r_glue_s3gen.c) -------------------------------------------------------------
+
+def _s3gen_call(lib, fd, hd, tok, ptok, pfeat, xvec, z, phase, snoise, bad=0, finalize=1):
+    from chatterbox_amd import synth as sy
+    FP, IP = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+    tok32, ptok32 = np.ascontiguousarray(tok, dtype=np.int32), np.ascontiguousarray(ptok, dtype=np.int32)
+    pf, xv, zz, ph, sn = f(pfeat), f(xvec), f(z[0]), f(phase), f(snoise)
+    cap = 2 * tok32.size
+    mel = np.zeros(hd.mel * cap, np.float32)
+    audio = np.zeros(cap * 480, np.float32)
+    n = C.c_int32(0)
+    p = lambda a, t=FP: None if a is None else a.ctypes.data_as(t)
+    rc = lib.mock_s3gen(sy.ensure_flow_checkpoint(fd, 555).encode(), sy.ensure_hift_checkpoint(hd, 999).encode(), p(tok32, IP), tok32.size,
+                        p(ptok32, IP), ptok32.size, p(pf), pf.shape[0], hd.mel, p(xv), xv.size, p(zz), zz.shape[1], 10, C.c_double(0.7), 0,
+                        finalize, p(ph), hd.n_harm, p(sn), bad, p(mel), cap, C.byref(n), p(audio))
+    T = n.value
+    return rc, mel[:hd.mel * T].reshape(1, hd.mel, T), audio[:T * 480]
+
+
+def test_s3gen_through_the_glue_equals_the_ctypes_path():
+    """tokens -> mel -> waveform through t3mi_r_flow_open / _flow_inference / _hift_open / _hift_inference, driven as `.Call`
+    drives them (integer ids, doubles for everything else, NULL for absent draws): the same bits as the ctypes path, whose
+    parity with the oracle tests/test_gpu_cfm.py holds; every refusal frees its C state and the finalizers close both handles."""
+    if not os.path.exists(LIB):
+        pytest.fail(f"{LIB} is not built (make -C tests/r_mock, or __graft_entry__.build())")
+    lib = C.CDLL(LIB)
+    lib.mock_last_error.restype = C.c_char_p
+    fd, hd = synth.FLOW_TINY, synth.HIFT_TINY
+    tok, ptok, pfeat, xvec, z = synth.synth_flow_inputs(fd, 12, 7, 4)
+    rng = np.random.default_rng(1)
+    phase = rng.uniform(-np.pi, np.pi, hd.n_harm).astype(np.float32)
+    snoise = rng.standard_normal((hd.n_harm, 24 * 480)).astype(np.float32)
+    rc, mel, audio = _s3gen_call(lib, fd, hd, tok, ptok, pfeat, xvec, z, phase, snoise)
+    assert rc == 0, lib.mock_last_error()
+    with cb.load_s3gen_flow(synth.ensure_flow_checkpoint(fd, 555)) as flow, cb.load_hift_vocoder(synth.ensure_hift_checkpoint(hd, 999)) as voc:
+        want_mel = flow.inference(tok, ptok, pfeat, xvec, z)
+        want = voc.inference(want_mel, phase, snoise)["audio"]
+        want_quiet = voc.inference(want_mel)["audio"]
+    assert mel.shape == want_mel.shape and np.array_equal(mel, want_mel)
+    assert np.array_equal(audio, want)
+    # NULL phase / noise = the zero-phase, noise-free source
+    rc, _, audio = _s3gen_call(lib, fd, hd, tok, ptok, pfeat, xvec, z, None, None)
+    assert rc == 0 and np.array_equal(audio, want_quiet)
+    # refusals: ids of the wrong R type, a short prompt mel, a short mel for the vocoder; an id outside the table is clamped (R/s3gen.R:833)
+    rc, _, _ = _s3gen_call(lib, fd, hd, tok, ptok, pfeat, xvec, z, phase, snoise, bad=1)
+    assert rc == -1 and b"integer vectors" in lib.mock_last_error()
+    rc, _, _ = _s3gen_call(lib, fd, hd, tok, ptok, pfeat, xvec, z, phase, snoise, bad=2)
+    assert rc == -1 and b"stated sizes" in lib.mock_last_error()
+    rc, _, _ = _s3gen_call(lib, fd, hd, tok, ptok, pfeat, xvec, z, phase, snoise, bad=4)
+    assert rc == -1 and b"stated sizes" in lib.mock_last_error()
+    rc, mel3, _ = _s3gen_call(lib, fd, hd, tok, ptok, pfeat, xvec, z, phase, snoise, bad=3)
+    t3 = np.array(tok).copy(); t3[0] = fd.vocab - 1
+    with cb.load_s3gen_flow(synth.ensure_flow_checkpoint(fd, 555)) as flow:
+        assert rc == 0 and np.array_equal(mel3, flow.inference(t3, ptok, pfeat, xvec, z))
+    assert lib.mock_protect_balance() == 0
