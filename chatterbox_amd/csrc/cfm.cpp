@@ -785,6 +785,10 @@ int t3mi_cfm_solve(t3mi_cfm* m, int T, const float* z, const float* mu, const fl
     return T3MI_OK;
 }
 
+// The relative-position term of the conformer attention is a [heads][2T][4T - 1] fp32 matrix: 17 GB at 8192 tokens (5.5 minutes of
+// speech); longer inputs are refused rather than left to fail in hipMalloc.
+static constexpr int kFlowMaxTokens = 8192;
+
 int t3mi_flow_open(const char* path, int device, t3mi_cfm** out) {
     if (!path || !out) return fail(T3MI_ERR_ARG, "t3mi_flow_open: null argument");
     *out = nullptr;
@@ -817,7 +821,7 @@ int t3mi_flow_encoder(t3mi_cfm* m, int T, const float* x, float* out) {
     int rc = check_handle(m);
     if (rc) return rc;
     if (!m->flow) return fail(T3MI_ERR_STATE, "not a flow handle (open it with t3mi_flow_open)");
-    if (!x || !out || T <= 0 || T > (1 << 16)) return fail(T3MI_ERR_ARG, "t3mi_flow_encoder: bad argument");
+    if (!x || !out || T <= 0 || T > kFlowMaxTokens) return fail(T3MI_ERR_ARG, "t3mi_flow_encoder: bad argument (1 .. 8192 tokens)");
     HIPCHK(hipSetDevice(m->device));
     if ((rc = flow_ws(m, T))) return rc;
     Flow* f = m->flow.get();
@@ -837,7 +841,8 @@ int t3mi_flow_inference(t3mi_cfm* m, const int32_t* token, int n_token, const in
     if (!m->flow) return fail(T3MI_ERR_STATE, "not a flow handle (open it with t3mi_flow_open)");
     if (!token || !prompt_token || !prompt_feat || !embedding || !noise || !out || !n_frames)
         return fail(T3MI_ERR_ARG, "t3mi_flow_inference: null argument");
-    if (n_token <= 0 || n_prompt < 0 || n_feat < 0 || n_token + n_prompt > (1 << 16)) return fail(T3MI_ERR_ARG, "t3mi_flow_inference: bad token counts");
+    if (n_token <= 0 || n_prompt < 0 || n_feat < 0 || n_token > kFlowMaxTokens || n_prompt > kFlowMaxTokens || n_token + n_prompt > kFlowMaxTokens)
+        return fail(T3MI_ERR_ARG, "t3mi_flow_inference: bad token counts (prompt + tokens must be 1 .. 8192)");
     HIPCHK(hipSetDevice(m->device));
     Flow* f = m->flow.get();
     const int T = n_prompt + n_token, mel = m->mel;
