@@ -288,7 +288,25 @@ int load_estimator(t3mi_cfm* m, const t3mi::SafeTensorsFile& st, const std::stri
 }
 
 // ---- one estimator call over the rows in the workspace -----------------------------------------------------------
-int gemm(t3mi_cfm* m, const float* A, const Lin& l, int M, int epi, float* y, const float* resid, float* yact) {
+// y = epi(LN?(A) W^T + b).  The dense fp32 kernel (dense_gemm.hip) takes every shape it accepts; `ln` fuses a LayerNorm over
+// A's K columns into its staging.  Other shapes (N = 80: final_proj, the time path's few rows) go through launch_gemm.
+static bool g_dense = getenv("T3MI_DENSE_GEMM") == nullptr || atoi(getenv("T3MI_DENSE_GEMM")) != 0;   // 0: A/B runs against launch_gemm
+
+int gemm(t3mi_cfm* m, const float* A, const Lin& l, int M, int epi, float* y, const float* resid, float* yact, const Norm* ln = nullptr,
+         float ln_eps = 1e-5f, float* ln_scratch = nullptr) {
+    if (g_dense && M >= 32 && t3k::dense_gemm_supported(M, l.N, l.K, epi) && (!ln || l.K <= 512)) {
+        t3k::DenseGemmArgs d;
+        d.A = A; d.lda = l.K; d.W = l.w; d.bias = l.b; d.M = M; d.N = l.N; d.K = l.K; d.epi = epi;
+        d.y = epi == t3k::EPI_GELU ? yact : y; d.ldy = l.N; d.resid = resid;
+        if (ln) { d.ln_w = ln->w; d.ln_b = ln->b; d.ln_eps = ln_eps; }
+        HIPCHK(t3k::launch_dense_gemm(d, m->stream));
+        return T3MI_OK;
+    }
+    if (ln) {   // the norm as a launch of its own
+        if (!ln_scratch) return fail(T3MI_ERR_STATE, "gemm: no scratch rows for the LayerNorm");
+        HIPCHK(t3k::launch_layernorm_rows(const_cast<float*>(A), ln->w, ln->b, ln_eps, ln_scratch, M, l.K, 0, m->stream));   // (ks = 0: x is only read)
+        A = ln_scratch;
+    }
     t3k::GemmArgs a;
     a.W = l.w; a.A = A; a.M = M; a.N = l.N; a.K = l.K; a.bias = l.b;
     a.y = y; a.resid = resid; a.ldy = l.N; a.yact = yact;
@@ -357,13 +375,11 @@ int resnet(t3mi_cfm* m, const Resnet& r, const float* x, int M, int T, float* ou
 // basic_transformer_block (R/s3gen.R:359-372), in place on x [M][C]
 int transformer(t3mi_cfm* m, const Tfm& t, float* x, int B, int T) {
     const int M = B * T, C = m->C;
-    HIPCHK(t3k::launch_layernorm_rows(x, t.n1.w, t.n1.b, 1e-5f, m->xn.p, M, C, 0, m->stream));
-    int rc = gemm(m, m->xn.f(), t.qkv, M, t3k::EPI_STORE, m->qkv.f(), nullptr, nullptr);
+    int rc = gemm(m, x, t.qkv, M, t3k::EPI_STORE, m->qkv.f(), nullptr, nullptr, &t.n1, 1e-5f, m->xn.f());   // norm1 fused into the staging
     if (rc) return rc;
     HIPCHK(t3k::launch_cfm_attn(m->qkv.f(), m->ao.f(), B, T, m->heads, 64, m->apo.f(), m->apml.f(), m->stream));
     if ((rc = gemm(m, m->ao.f(), t.out, M, t3k::EPI_RESID, x, x, nullptr))) return rc;
-    HIPCHK(t3k::launch_layernorm_rows(x, t.n3.w, t.n3.b, 1e-5f, m->xn.p, M, C, 0, m->stream));
-    if ((rc = gemm(m, m->xn.f(), t.ff1, M, t3k::EPI_GELU, nullptr, nullptr, m->ffb.f()))) return rc;
+    if ((rc = gemm(m, x, t.ff1, M, t3k::EPI_GELU, nullptr, nullptr, m->ffb.f(), &t.n3, 1e-5f, m->xn.f()))) return rc;
     return gemm(m, m->ffb.f(), t.ff2, M, t3k::EPI_RESID, x, x, nullptr);
 }
 

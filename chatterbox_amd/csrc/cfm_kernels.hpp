@@ -37,4 +37,25 @@ hipError_t launch_cfm_time_sin(const float* t, float* out, int B, int dim, float
 hipError_t launch_cfm_euler(float* x, const float* d_cond, const float* d_uncond, size_t n, float dt, float one_plus_rate, float rate,
                             hipStream_t s);
 
+// Dense fp32 GEMM for the S3Gen shapes (a few hundred to a few thousand rows, K and N of 256 .. 1536): y = epi(LN?(A) W^T + b).
+// Exact-fp32 MFMA products.  ln_w / ln_b (both or neither): LayerNorm over the K columns of every A row (K = the row width)
+// applied while the rows are staged, so a LayerNorm in front of a linear layer has no launch of its own.  resid may alias y.
+struct DenseGemmArgs {
+    const float* A = nullptr;      // [M][lda]
+    int lda = 0;
+    const float* W = nullptr;      // [N][K] row-major, as the checkpoint stores nn_linear weights
+    const float* bias = nullptr;   // [N] or nullptr
+    float* y = nullptr;            // [M][ldy]
+    int ldy = 0;
+    const float* resid = nullptr;  // epi 1: [M][ldy]
+    const float* ln_w = nullptr;
+    const float* ln_b = nullptr;
+    float ln_eps = 1e-5f;
+    int M = 0, N = 0, K = 0;
+    int epi = 0;                   // EPI_STORE (0), EPI_RESID (1: resid + acc + bias), EPI_GELU (4: gelu_tanh(acc + bias))
+};
+// true when launch_dense_gemm takes the shape (N % 32 == 0, K % 64 == 0, epi one of the three)
+bool dense_gemm_supported(int M, int N, int K, int epi);
+hipError_t launch_dense_gemm(const DenseGemmArgs& a, hipStream_t s);
+
 }  // namespace t3k
