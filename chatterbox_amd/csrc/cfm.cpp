@@ -50,6 +50,7 @@ struct Buf {
 struct Lin {          // y = A W^T + b ; W [N][K] row-major on device
     const float* w = nullptr;
     const float* b = nullptr;
+    const float* colsum = nullptr;   // != nullptr: the LayerNorm in front of the layer is folded into w / b (cfm_kernels.hpp, DenseGemmArgs)
     int N = 0, K = 0;
 };
 struct Norm {
@@ -66,7 +67,7 @@ struct Resnet {
     int cin = 0;
 };
 struct Tfm {
-    Norm n1, n3;
+    // (norm1 and norm3 are folded into qkv and ff1 by the loader)
     Lin qkv, out, ff1, ff2;
 };
 
@@ -249,18 +250,34 @@ int load_estimator(t3mi_cfm* m, const t3mi::SafeTensorsFile& st, const std::stri
         if (ok) norm(r.b2.norm, p + "block2.block.2", C);
         if (ok) conv(r.res, p + "res_conv", C, cin, 1);
     };
+    // the LayerNorm `nkey` in front of the linear layer at host offset ow (bias at ob, or -1) is folded into it
+    // (dense_fold_layernorm): the layer's bias and column sums are new host arrays
+    auto fold = [&](Lin& l, long long ow, long long ob, const std::string& nkey) {
+        const long long lw = L.put(nkey + ".weight", {l.K});
+        const long long lb = lw >= 0 ? L.put(nkey + ".bias", {l.K}) : -1;
+        if (lb < 0) { ok = false; return; }
+        const size_t npad = ((size_t)l.N + 3) & ~size_t(3), ob2 = L.host.size();
+        L.host.resize(ob2 + 2 * npad);
+        float* H = L.host.data();
+        t3k::dense_fold_layernorm(H + ow, ob >= 0 ? H + ob : nullptr, H + lw, H + lb, l.N, l.K, H + ob2, H + ob2 + npad);
+        reg(&l.w, ow);
+        reg(&l.b, (long long)ob2);
+        reg(&l.colsum, (long long)(ob2 + npad));
+    };
     auto tfm = [&](Tfm& t, const std::string& p) {
-        norm(t.n1, p + "norm1", C);
-        // to_q | to_k | to_v stacked [3 * inner][C]: one GEMM, the layout cfm_attn_kernel reads
+        // to_q | to_k | to_v stacked [3 * inner][C]: one GEMM, the layout cfm_attn_kernel reads; norm1 folded in
         t.qkv.N = 3 * m->inner; t.qkv.K = C;
         const long long oq = ok ? L.put(p + "attn1.to_q.weight", {m->inner, C}) : -1;
         const long long ok_ = oq >= 0 ? L.put(p + "attn1.to_k.weight", {m->inner, C}) : -1;
         const long long ov = ok_ >= 0 ? L.put(p + "attn1.to_v.weight", {m->inner, C}) : -1;
         if (ov < 0) { ok = false; return; }
-        reg(&t.qkv.w, oq);
-        lin(t.out, p + "attn1.to_out.0", C, m->inner, true);
-        if (ok) norm(t.n3, p + "norm3", C);
-        if (ok) lin(t.ff1, p + "ff.net.0.proj", m->ff, C, true);
+        fold(t.qkv, oq, -1, p + "norm1");
+        if (ok) lin(t.out, p + "attn1.to_out.0", C, m->inner, true);
+        t.ff1.N = m->ff; t.ff1.K = C;
+        const long long o1 = ok ? L.put(p + "ff.net.0.proj.weight", {m->ff, C}) : -1;
+        const long long b1 = o1 >= 0 ? L.put(p + "ff.net.0.proj.bias", {m->ff}) : -1;
+        if (b1 < 0) { ok = false; return; }
+        fold(t.ff1, o1, b1, p + "norm3");
         if (ok) lin(t.ff2, p + "ff.net.2", C, m->ff, true);
     };
     if (ok) resnet(m->resnets[0], "down_blocks.0.0.", m->in_ch, 0);
@@ -288,25 +305,18 @@ int load_estimator(t3mi_cfm* m, const t3mi::SafeTensorsFile& st, const std::stri
 }
 
 // ---- one estimator call over the rows in the workspace -----------------------------------------------------------
-// y = epi(LN?(A) W^T + b).  The dense fp32 kernel (dense_gemm.hip) takes every shape it accepts; `ln` fuses a LayerNorm over
-// A's K columns into its staging.  Other shapes (N = 80: final_proj, the time path's few rows) go through launch_gemm.
-static bool g_dense = getenv("T3MI_DENSE_GEMM") == nullptr || atoi(getenv("T3MI_DENSE_GEMM")) != 0;   // 0: A/B runs against launch_gemm
-
-int gemm(t3mi_cfm* m, const float* A, const Lin& l, int M, int epi, float* y, const float* resid, float* yact, const Norm* ln = nullptr,
-         float ln_eps = 1e-5f, float* ln_scratch = nullptr) {
-    if (g_dense && M >= 32 && t3k::dense_gemm_supported(M, l.N, l.K, epi) && (!ln || l.K <= 512)) {
+// y = epi(LN?(A) W^T + b).  The dense fp32 kernel (dense_gemm.hip) takes every shape it accepts (a layer with a folded LayerNorm
+// runs nowhere else); the rest (N = 80: final_proj; the time path's few rows) goes through launch_gemm.
+int gemm(t3mi_cfm* m, const float* A, const Lin& l, int M, int epi, float* y, const float* resid, float* yact, float ln_eps = 1e-5f) {
+    if ((M >= 16 || l.colsum) && t3k::dense_gemm_supported(M, l.N, l.K, epi)) {
         t3k::DenseGemmArgs d;
         d.A = A; d.lda = l.K; d.W = l.w; d.bias = l.b; d.M = M; d.N = l.N; d.K = l.K; d.epi = epi;
         d.y = epi == t3k::EPI_GELU ? yact : y; d.ldy = l.N; d.resid = resid;
-        if (ln) { d.ln_w = ln->w; d.ln_b = ln->b; d.ln_eps = ln_eps; }
+        d.ln_colsum = l.colsum; d.ln_eps = ln_eps;
         HIPCHK(t3k::launch_dense_gemm(d, m->stream));
         return T3MI_OK;
     }
-    if (ln) {   // the norm as a launch of its own
-        if (!ln_scratch) return fail(T3MI_ERR_STATE, "gemm: no scratch rows for the LayerNorm");
-        HIPCHK(t3k::launch_layernorm_rows(const_cast<float*>(A), ln->w, ln->b, ln_eps, ln_scratch, M, l.K, 0, m->stream));   // (ks = 0: x is only read)
-        A = ln_scratch;
-    }
+    if (l.colsum) return fail(T3MI_ERR_STATE, "a layer with a folded LayerNorm has a shape the dense GEMM does not take (N % 32, K % 64)");
     t3k::GemmArgs a;
     a.W = l.w; a.A = A; a.M = M; a.N = l.N; a.K = l.K; a.bias = l.b;
     a.y = y; a.resid = resid; a.ldy = l.N; a.yact = yact;
@@ -374,12 +384,12 @@ int resnet(t3mi_cfm* m, const Resnet& r, const float* x, int M, int T, float* ou
 
 // basic_transformer_block (R/s3gen.R:359-372), in place on x [M][C]
 int transformer(t3mi_cfm* m, const Tfm& t, float* x, int B, int T) {
-    const int M = B * T, C = m->C;
-    int rc = gemm(m, x, t.qkv, M, t3k::EPI_STORE, m->qkv.f(), nullptr, nullptr, &t.n1, 1e-5f, m->xn.f());   // norm1 fused into the staging
+    const int M = B * T;
+    int rc = gemm(m, x, t.qkv, M, t3k::EPI_STORE, m->qkv.f(), nullptr, nullptr);   // norm1 folded into the layer
     if (rc) return rc;
     HIPCHK(t3k::launch_cfm_attn(m->qkv.f(), m->ao.f(), B, T, m->heads, 64, m->apo.f(), m->apml.f(), m->stream));
     if ((rc = gemm(m, m->ao.f(), t.out, M, t3k::EPI_RESID, x, x, nullptr))) return rc;
-    if ((rc = gemm(m, x, t.ff1, M, t3k::EPI_GELU, nullptr, nullptr, m->ffb.f(), &t.n3, 1e-5f, m->xn.f()))) return rc;
+    if ((rc = gemm(m, x, t.ff1, M, t3k::EPI_GELU, nullptr, nullptr, m->ffb.f()))) return rc;   // norm3 folded
     return gemm(m, m->ffb.f(), t.ff2, M, t3k::EPI_RESID, x, x, nullptr);
 }
 
@@ -569,6 +579,13 @@ int flow_ws(t3mi_cfm* m, int T) {   // T = tokens; the up stage runs at 2T
 
 int fgemm(t3mi_cfm* m, const float* A, const Lin& l, int M, int epi, float* y, const float* resid) {
     Flow* f = m->flow.get();
+    if (M >= 16 && t3k::dense_gemm_supported(M, l.N, l.K, epi)) {
+        t3k::DenseGemmArgs d;
+        d.A = A; d.lda = l.K; d.W = l.w; d.bias = l.b; d.M = M; d.N = l.N; d.K = l.K; d.epi = epi;
+        d.y = y; d.ldy = l.N; d.resid = resid;
+        HIPCHK(t3k::launch_dense_gemm(d, m->stream));
+        return T3MI_OK;
+    }
     t3k::GemmArgs a;
     a.W = l.w; a.A = A; a.M = M; a.N = l.N; a.K = l.K; a.bias = l.b;
     a.y = y; a.resid = resid; a.ldy = l.N;

@@ -38,8 +38,10 @@ hipError_t launch_cfm_euler(float* x, const float* d_cond, const float* d_uncond
                             hipStream_t s);
 
 // Dense fp32 GEMM for the S3Gen shapes (a few hundred to a few thousand rows, K and N of 256 .. 1536): y = epi(LN?(A) W^T + b).
-// Exact-fp32 MFMA products.  ln_w / ln_b (both or neither): LayerNorm over the K columns of every A row (K = the row width)
-// applied while the rows are staged, so a LayerNorm in front of a linear layer has no launch of its own.  resid may alias y.
+// Exact-fp32 MFMA products.  ln_colsum != nullptr: a LayerNorm over the K columns of every A row (K = the row width) sits in
+// front of the layer and has been FOLDED into it by the loader -- W holds W diag(w_ln), bias holds b + W b_ln, ln_colsum[n] =
+// sum_k W'[n][k] -- so that LN(x) W^T + b = rstd (W' x - mean ln_colsum) + bias: the kernel multiplies the raw rows and its
+// epilogue applies the row statistics it computed on the way (dense_fold_layernorm does the folding).  resid may alias y.
 struct DenseGemmArgs {
     const float* A = nullptr;      // [M][lda]
     int lda = 0;
@@ -48,14 +50,16 @@ struct DenseGemmArgs {
     float* y = nullptr;            // [M][ldy]
     int ldy = 0;
     const float* resid = nullptr;  // epi 1: [M][ldy]
-    const float* ln_w = nullptr;
-    const float* ln_b = nullptr;
+    const float* ln_colsum = nullptr;   // [N]
     float ln_eps = 1e-5f;
     int M = 0, N = 0, K = 0;
     int epi = 0;                   // EPI_STORE (0), EPI_RESID (1: resid + acc + bias), EPI_GELU (4: gelu_tanh(acc + bias))
 };
 // true when launch_dense_gemm takes the shape (N % 32 == 0, K % 64 == 0, epi one of the three)
 bool dense_gemm_supported(int M, int N, int K, int epi);
+// Host side of the fold, on fp32 host copies: W [N][K] in place -> W diag(w_ln); bias_out [N] = (bias or 0) + W b_ln (with the
+// ORIGINAL W); colsum_out [N] = row sums of the folded W.  Sums in double.
+void dense_fold_layernorm(float* W, const float* bias, const float* ln_w, const float* ln_b, int N, int K, float* bias_out, float* colsum_out);
 hipError_t launch_dense_gemm(const DenseGemmArgs& a, hipStream_t s);
 
 }  // namespace t3k

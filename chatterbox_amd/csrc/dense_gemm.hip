@@ -5,10 +5,10 @@
 // The decoder's many-row kernels (batch_kernels.hip) are built for a weight STREAM from HBM shared by <= 128 rows; here the
 // operands are a megabyte each and live in L2, M is 10^2 .. 10^4 rows and a GEMM is 0.3 - 0.8 GFLOP, i.e. 2 - 5 us of the
 // exact-fp32 matrix-core time (v_mfma_f32_16x16x4_f32, 256 FLOP / clk / CU).  What decides is how many CUs work and how
-// little each block waits, so: small blocks (4 waves, a BM x BN tile of 32 x 64, 32 x 32 or 64 x 64: 256 - 512 blocks at
-// 1000 rows), 35 - 70 KB of LDS so that two to four blocks share a CU and cover each other's staging, 64-k chunks of both
-// operands double-buffered in LDS with ONE barrier per chunk, the next chunk's global loads in flight under the current
-// chunk's MFMAs (unconditional, clamped: exact wait counts).  Rows of both tiles sit at a stride of 68 floats (272 B), the
+// little each block waits, so: small blocks (4 waves, a BM x BN tile of 32 x 32 or 32 x 64: 256 - 1536 blocks at
+// 1000 rows), 35 - 52 KB of LDS so that three to four blocks share a CU and cover each other's staging, 64-k chunks of both
+// operands double-buffered in LDS with ONE barrier per chunk, the next chunks' global loads in flight under the current
+// chunk's MFMAs in a register ring (no load under a condition: exact wait counts).  Rows of both tiles sit at a stride of 68 floats (272 B), the
 // 16 rows of a fragment read fall into distinct banks.
 //
 // MFMA operand roles: the WEIGHT rows are the MFMA's row operand and the activation rows its column operand, so a lane ends
@@ -16,10 +16,14 @@
 // element k = 16 j + 4 g + i of its row into MFMA i of k-group j -- a fixed permutation of the dot product's terms,
 // the same for both operands.
 //
-// LN: a LayerNorm over the K columns of every A row (K = the row width; basic_transformer_block's norm1 / norm3,
-// R/s3gen.R:359-372; the conformer's norm_mha / norm_ff) is applied while the A chunks are staged: the block first reads its
-// BM rows once for mean and variance (two passes over registers), so the norm has no launch of its own and the normalised
-// rows never go through HBM / L2.
+// LN: a LayerNorm over the K columns of every A row in front of the linear layer (K = the row width; basic_transformer_block's
+// norm1 / norm3, R/s3gen.R:359-372; the conformer's norm_mha / norm_ff) has no launch of its own and costs the multiply loop
+// nothing: with W' = W diag(w_ln), s = W' 1 and b' = b + W b_ln (all three made once, when the checkpoint is loaded),
+//     LN(x) W^T + b = rstd (W' x - mean s) + b',
+// so the GEMM runs on the raw rows and the epilogue applies the row's mean and rstd.  The statistics (two-pass: mean, then the
+// centred squares) come from the staging registers when the whole K range is in the ring (K <= 64 D), else from a second read
+// of the rows.  A first form normalised the rows while staging them: 32 more VALU instructions and two LDS reads per chunk
+// and thread made every such GEMM 25 - 30 % slower (scripts/micro/dense_micro.hip: ff1 8.3 -> 10.7 us at 1000 rows).
 #include "cfm_kernels.hpp"
 #include "kernels.hpp"
 
@@ -33,12 +37,8 @@ namespace t3k {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#ifndef T3K_DENSE_LN_VARIANT
-#define T3K_DENSE_LN_VARIANT 0   // micro-benchmark builds only: 1 = no statistics (mu 0, rstd 1), 2 = statistics but rows staged as they are
-#endif
 constexpr int kKC = 64;          // k per chunk
 constexpr int kLdT = kKC + 4;    // LDS row stride in floats
-constexpr int kDenseLnMaxK = 512; // widest row a fused LayerNorm takes (its weight and bias sit in LDS)
 
 // sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), every lane gets it: VALU moves, no LDS round trip
 template <int CTRL> __device__ __forceinline__ float dg_dpp(float v) {
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(DenseGemmArgs a) {
     constexpr int MT = BM / 32, NT = BN / 32;        // 16-row / 16-feature tiles per wave (waves sit 2 x 2)
     constexpr int NLD = (BM + BN) / 16;              // staging pieces (16 B) per thread and chunk
     constexpr int NLA = BM / 16;                     // of which activation rows
-    extern __shared__ __attribute__((aligned(16))) float dg_lds[];   // [2][(BM + BN)][kLdT], then LayerNorm w | b [K] each
-    float* lnw_s = dg_lds + 2 * (BM + BN) * kLdT;
+    extern __shared__ __attribute__((aligned(16))) float dg_lds[];   // [2][(BM + BN)][kLdT], then (LN) mean | rstd of the BM rows
+    float* stat = dg_lds + 2 * (BM + BN) * kLdT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = lane & 15, g = lane >> 4;
     const int wm = wave & 1, wn = wave >> 1;
@@ -96,94 +96,49 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(DenseGemmArgs a) {
     };
     using std::integral_constant;
     auto fetch = [&](int c, auto SC) { fetch_part(c, SC, integral_constant<int, 0>{}, integral_constant<int, NLD>{}); };
-    float mu[NLA], rs[NLA];
-    auto stash = [&](int c, int buf, auto SC) {
+    auto stash = [&](int buf, auto SC) {
         constexpr int slot = decltype(SC)::value;
         float* d = dg_lds + (size_t)buf * (BM + BN) * kLdT + sr * kLdT + sc;
-        f32x4 lw = {1.f, 1.f, 1.f, 1.f}, lb = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (LN) {
-            lw = *reinterpret_cast<const f32x4*>(lnw_s + c * kKC + sc);
-            lb = *reinterpret_cast<const f32x4*>(lnw_s + K + c * kKC + sc);
-        }
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            f32x4 v = st[slot][i];
-            if constexpr (LN) {
-#if T3K_DENSE_LN_VARIANT != 2
-                if (i < NLA) v = (v - mu[i < NLA ? i : 0]) * rs[i < NLA ? i : 0] * lw + lb;
-#endif
-            }
-            *reinterpret_cast<f32x4*>(d + i * 16 * kLdT) = v;
-        }
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<f32x4*>(d + i * 16 * kLdT) = st[slot][i];
     };
-    // prologue: chunks 0 .. D - 1 into the ring.  With a LayerNorm the activation pieces of all D chunks go first (loads complete
-    // in order): the statistics wait for them only, the weight pieces arrive under the statistics and the first MFMAs.
-    f32x4 lnw_v = {0.f, 0.f, 0.f, 0.f}, lnb_v = {0.f, 0.f, 0.f, 0.f};
+    // prologue: chunks 0 .. D - 1 into the ring
+    static_for<D>([&](auto SC) { fetch(decltype(SC)::value, SC); });
     if constexpr (LN) {
-        const int i4 = tid < K / 4 ? tid : K / 4 - 1;   // K <= 1024: one 16-byte piece per thread covers the norm's weight and bias
-        lnw_v = *reinterpret_cast<const f32x4*>(a.ln_w + 4 * i4);
-        lnb_v = *reinterpret_cast<const f32x4*>(a.ln_b + 4 * i4);
-        static_for<D>([&](auto SC) { fetch_part(decltype(SC)::value, SC, integral_constant<int, 0>{}, integral_constant<int, NLA>{}); });
-        static_for<D>([&](auto SC) { fetch_part(decltype(SC)::value, SC, integral_constant<int, NLA>{}, integral_constant<int, NLD>{}); });
-    } else {
-        static_for<D>([&](auto SC) { fetch(decltype(SC)::value, SC); });
-    }
-    if constexpr (LN) {
-        if (tid < K / 4) {   // read from LDS when a chunk is stashed
-            *reinterpret_cast<f32x4*>(lnw_s + 4 * tid) = lnw_v;
-            *reinterpret_cast<f32x4*>(lnw_s + K + 4 * tid) = lnb_v;
-        }
-        // row statistics (two-pass: mean, then the centred squares).  The 16 threads that stage a row (tid & 15) hold all of it
-        // when the whole K range is in the ring; otherwise they read the row again (L2-resident), twice.
+        // row statistics for the epilogue: the 16 threads that stage a row (tid & 15, one DPP row) hold all of it when the whole
+        // K range is in the ring; otherwise they read it again (L2-resident), twice
         const float invK = 1.0f / (float)K;
-#if T3K_DENSE_LN_VARIANT == 1
-        for (int i = 0; i < NLA; ++i) { mu[i] = 0.f; rs[i] = 1.f; }
-        if (false) {
-#else
-        if (nc <= D) {
-#endif
 #pragma unroll
-            for (int i = 0; i < NLA; ++i) {
-                float sum = 0.f;
+        for (int i = 0; i < NLA; ++i) {
+            float sum = 0.f, sq = 0.f, mean;
+            if (nc <= D) {   // (block-uniform; nc % D == 0: every slot holds a distinct chunk)
 #pragma unroll
-                for (int s = 0; s < D; ++s)
-                    if (s < nc) sum += (st[s][i].x + st[s][i].y) + (st[s][i].z + st[s][i].w);
-                sum = row16_sum(sum);
-                const float mean = sum * invK;
-                float sq = 0.f;
+                for (int s = 0; s < D; ++s) sum += (st[s][i].x + st[s][i].y) + (st[s][i].z + st[s][i].w);
+                mean = row16_sum(sum) * invK;
 #pragma unroll
-                for (int s = 0; s < D; ++s)
-                    if (s < nc) {
-                        const f32x4 dl = st[s][i] - mean;
-                        sq += (dl.x * dl.x + dl.y * dl.y) + (dl.z * dl.z + dl.w * dl.w);
-                    }
-                sq = row16_sum(sq);
-                mu[i] = mean;
-                rs[i] = 1.0f / sqrtf(sq * invK + a.ln_eps);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NLA; ++i) {
-                float sum = 0.f;
+                for (int s = 0; s < D; ++s) {
+                    const f32x4 dl = st[s][i] - mean;
+                    sq += (dl.x * dl.x + dl.y * dl.y) + (dl.z * dl.z + dl.w * dl.w);
+                }
+            } else {
                 for (int c = 0; c < nc; ++c) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(src[i] + c * kKC);
                     sum += (v.x + v.y) + (v.z + v.w);
                 }
-                sum = row16_sum(sum);
-                const float mean = sum * invK;
-                float sq = 0.f;
+                mean = row16_sum(sum) * invK;
                 for (int c = 0; c < nc; ++c) {
                     const f32x4 dl = *reinterpret_cast<const f32x4*>(src[i] + c * kKC) - mean;
                     sq += (dl.x * dl.x + dl.y * dl.y) + (dl.z * dl.z + dl.w * dl.w);
                 }
-                sq = row16_sum(sq);
-                mu[i] = mean;
-                rs[i] = 1.0f / sqrtf(sq * invK + a.ln_eps);
+            }
+            sq = row16_sum(sq);
+            if ((tid & 15) == 0) {   // read after the loop's barriers
+                stat[sr + 16 * i] = mean;
+                stat[BM + sr + 16 * i] = 1.0f / sqrtf(sq * invK + a.ln_eps);
             }
         }
-        __syncthreads();   // the norm's weights are in LDS
     }
-    stash(0, 0, integral_constant<int, 0>{});
+    stash(0, integral_constant<int, 0>{});
     __syncthreads();
 
     f32x4 acc[MT][NT];
@@ -200,9 +155,6 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(DenseGemmArgs a) {
         constexpr int d = decltype(DC)::value;
         constexpr int nslot = (d + 1) % D;
         if constexpr (decltype(REFILL)::value) fetch(cc + D, integral_constant<int, d>{});
-#ifdef T3K_DENSE_STASH_FIRST
-        if constexpr (!decltype(LAST)::value) stash(cc + 1, (cc + 1) & 1, integral_constant<int, nslot>{});
-#endif
         const float* b = dg_lds + (size_t)(cc & 1) * (BM + BN) * kLdT;
 #pragma unroll
         for (int j = 0; j < kKC / 16; ++j) {
@@ -220,9 +172,7 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(DenseGemmArgs a) {
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[tn][i], av[tm][i], acc[tm][tn], 0, 0, 0);
         }
         if constexpr (!decltype(LAST)::value) {
-#ifndef T3K_DENSE_STASH_FIRST
-            stash(cc + 1, (cc + 1) & 1, integral_constant<int, nslot>{});
-#endif
+            stash((cc + 1) & 1, integral_constant<int, nslot>{});
             __syncthreads();
         }
     };
@@ -242,6 +192,13 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(DenseGemmArgs a) {
         for (int tn = 0; tn < NT; ++tn) {
             const int f = n0 + wn * (BN / 2) + 16 * tn + 4 * g;
             f32x4 v = acc[tm][tn];
+            if constexpr (LN) {   // rstd (W' x - mean s); the bias below is b' = b + W b_ln
+                const int rl = wm * (BM / 2) + 16 * tm + nl;
+                const float mean = stat[rl], rstd = stat[BM + rl];
+                const f32x4 cs = *reinterpret_cast<const f32x4*>(a.ln_colsum + f);
+                v.x = __fmul_rn(rstd, __fsub_rn(v.x, __fmul_rn(mean, cs.x))); v.y = __fmul_rn(rstd, __fsub_rn(v.y, __fmul_rn(mean, cs.y)));
+                v.z = __fmul_rn(rstd, __fsub_rn(v.z, __fmul_rn(mean, cs.z))); v.w = __fmul_rn(rstd, __fsub_rn(v.w, __fmul_rn(mean, cs.w)));
+            }
             if (a.bias != nullptr) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + f);
                 v.x = __fadd_rn(v.x, bv.x); v.y = __fadd_rn(v.y, bv.y); v.z = __fadd_rn(v.z, bv.z); v.w = __fadd_rn(v.w, bv.w);
@@ -268,14 +225,14 @@ __global__ __launch_bounds__(256) void dense_gemm_kernel(DenseGemmArgs a) {
 
 template <int BM, int BN, int EPI, bool LN, int D>
 hipError_t launch_dense_d(const DenseGemmArgs& a, hipStream_t s) {
-    const int lds = (2 * (BM + BN) * kLdT + (LN ? 2 * a.K : 0)) * 4;
+    constexpr int lds = (2 * (BM + BN) * kLdT + (LN ? 2 * BM : 0)) * 4;
     static bool attr_done[64] = {};   // one flag per instantiation and device
     int dev = 0;
     hipError_t ed = hipGetDevice(&dev);
     if (ed != hipSuccess) return ed;
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
         hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(dense_gemm_kernel<BM, BN, EPI, LN, D>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (BM + BN) * kLdT + 2 * kDenseLnMaxK) * 4);
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e0 != hipSuccess) return e0;
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
@@ -283,28 +240,31 @@ hipError_t launch_dense_d(const DenseGemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// ring depth: as deep as the registers allow (DMAX chunks), a divisor of the chunk count
-template <int BM, int BN, int EPI, bool LN, int DMAX>
+// Ring depth: a divisor of the chunk count.  Measured (dense_micro, 200 - 4000 rows): 2 chunks in flight are as good as 4 or 8
+// and a depth of 1 costs 10 - 25 %; with a LayerNorm the depth that holds the whole row (4 for K = 256, 8 for K = 512) saves the
+// second read of the rows.
+template <int BM, int BN, int EPI, bool LN>
 hipError_t launch_dense_v(const DenseGemmArgs& a, hipStream_t s) {
     const int nc = a.K / kKC;
-    if constexpr (DMAX >= 8) {
-        if (nc % 8 == 0) return launch_dense_d<BM, BN, EPI, LN, 8>(a, s);
+    if constexpr (LN) {
+        if constexpr (BM + BN <= 64) {
+            if (nc == 8) return launch_dense_d<BM, BN, EPI, LN, 8>(a, s);
+        }
+        if (nc == 4) return launch_dense_d<BM, BN, EPI, LN, 4>(a, s);
     }
-    if (nc % 4 == 0) return launch_dense_d<BM, BN, EPI, LN, 4>(a, s);
+    if (nc % 2 == 0) return launch_dense_d<BM, BN, EPI, LN, 2>(a, s);
     if (nc % 3 == 0) return launch_dense_d<BM, BN, EPI, LN, 3>(a, s);
     if (nc % 5 == 0) return launch_dense_d<BM, BN, EPI, LN, 5>(a, s);
-    if (nc % 2 == 0) return launch_dense_d<BM, BN, EPI, LN, 2>(a, s);
     return launch_dense_d<BM, BN, EPI, LN, 1>(a, s);
 }
 
 template <int EPI, bool LN>
 hipError_t launch_dense_e(const DenseGemmArgs& a, hipStream_t s) {
-    // tile by the number of blocks it leaves: 64 x 64 from 1024 blocks (operand traffic per product halves), else 32 x 64 for
-    // wide outputs and 32 x 32 for narrow ones (N = 256 at 1000 rows: 256 blocks)
-    const long long rows32 = (a.M + 31) / 32;
-    if (a.N % 64 == 0 && (long long)((a.M + 63) / 64) * (a.N / 64) >= 1024) return launch_dense_v<64, 64, EPI, LN, 4>(a, s);
-    if (a.N % 64 == 0 && rows32 * (a.N / 64) >= 320) return launch_dense_v<32, 64, EPI, LN, 4>(a, s);
-    return launch_dense_v<32, 32, EPI, LN, 8>(a, s);
+    // Tile: 32 x 32 (one accumulator tile per wave) is the fastest or tied on every estimator shape from 200 to 4000 rows except
+    // narrow outputs with many rows (N = 256 from 2000 rows: 32 x 64 saves 1 - 1.5 us); 64 x 64 was never the fastest
+    // (profiles/r03_dense_gemm_micro.txt).
+    if (a.N % 64 == 0 && a.N <= 512 && a.M >= 1536) return launch_dense_v<32, 64, EPI, LN>(a, s);
+    return launch_dense_v<32, 32, EPI, LN>(a, s);
 }
 
 }  // namespace
@@ -313,12 +273,25 @@ bool dense_gemm_supported(int M, int N, int K, int epi) {
     return M > 0 && N > 0 && K > 0 && N % 32 == 0 && K % kKC == 0 && (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_GELU);
 }
 
+void dense_fold_layernorm(float* W, const float* bias, const float* ln_w, const float* ln_b, int N, int K, float* bias_out, float* colsum_out) {
+    for (int n = 0; n < N; ++n) {
+        float* w = W + (size_t)n * K;
+        double sb = 0.0, sw = 0.0;
+        for (int k = 0; k < K; ++k) {
+            sb += (double)w[k] * (double)ln_b[k];
+            w[k] = w[k] * ln_w[k];
+            sw += (double)w[k];
+        }
+        bias_out[n] = (float)((bias ? (double)bias[n] : 0.0) + sb);
+        colsum_out[n] = (float)sw;
+    }
+}
+
 hipError_t launch_dense_gemm(const DenseGemmArgs& a, hipStream_t s) {
     if (!dense_gemm_supported(a.M, a.N, a.K, a.epi) || !a.A || !a.W || !a.y || a.lda < a.K || a.ldy < a.N) return hipErrorInvalidValue;
     if ((a.lda & 3) || (a.ldy & 3)) return hipErrorInvalidValue;           // 16-byte accesses
     if (a.epi == EPI_RESID && !a.resid) return hipErrorInvalidValue;
-    const bool ln = a.ln_w != nullptr;
-    if (ln && (!a.ln_b || a.K > kDenseLnMaxK)) return hipErrorInvalidValue;
+    const bool ln = a.ln_colsum != nullptr;
     switch (a.epi) {
         case EPI_STORE: return ln ? launch_dense_e<EPI_STORE, true>(a, s) : launch_dense_e<EPI_STORE, false>(a, s);
         case EPI_RESID: return ln ? launch_dense_e<EPI_RESID, true>(a, s) : launch_dense_e<EPI_RESID, false>(a, s);

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "cfm_kernels.hpp"
 #include "hift_kernels.hpp"
 #include "kernels.hpp"
 #include "safetensors.hpp"
@@ -304,10 +305,18 @@ int conv_rows(t3mi_hift* m, const Conv& c, const float* x, int L_in, int ldx, in
     a.x = x; a.L_in = L_in; a.C = c.C; a.ldx = ldx; a.col = m->col.f(); a.L_out = L_out; a.k = c.k; a.Kp = c.Kp;
     a.stride = ws.stride; a.dil = ws.dil; a.pad = ws.pad; a.up = ws.up; a.act = ws.act; a.slope = ws.slope; a.alpha = ws.alpha;
     HIPCHK(t3k::launch_hift_window(a, m->stream));
+    const int epi = resid ? t3k::EPI_RESID : t3k::EPI_STORE;
+    if (L_out >= 16 && t3k::dense_gemm_supported(L_out, c.N, c.Kp, epi)) {   // everything but conv_post (N = 18) and the F0 classifier
+        t3k::DenseGemmArgs d;
+        d.A = m->col.f(); d.lda = c.Kp; d.W = c.w; d.bias = c.b; d.M = L_out; d.N = c.N; d.K = c.Kp; d.epi = epi;
+        d.y = y; d.ldy = c.N; d.resid = resid;
+        HIPCHK(t3k::launch_dense_gemm(d, m->stream));
+        return T3MI_OK;
+    }
     t3k::GemmArgs g;
     g.W = c.w; g.A = m->col.f(); g.M = L_out; g.N = c.N; g.K = c.Kp; g.bias = c.b;
     g.y = y; g.resid = resid; g.ldy = c.N;
-    HIPCHK(t3k::launch_gemm(g, resid ? t3k::EPI_RESID : t3k::EPI_STORE, 0, m->stream));
+    HIPCHK(t3k::launch_gemm(g, epi, 0, m->stream));
     return T3MI_OK;
 }
 
