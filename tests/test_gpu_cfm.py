@@ -275,3 +275,37 @@ def test_s3gen_inference_tokens_to_waveform():
     assert np.abs(audio[480:960] - ref_audio[480:960] * ramp).max() < TOL
     assert np.abs(audio[960:] - ref_audio[960:]).max() < TOL
     assert tm["flow_ms"] > 0 and tm["vocoder_ms"] > 0
+
+
+def test_estimator_many_rows_and_large_row_means(tmp_path):
+    """Round 3, the dense GEMM (csrc/dense_gemm.hip): (i) 1800 rows -- the 32 x 64 tile that narrow outputs take from 1536 rows,
+    several key tiles and key splits in the attention, a last row block of 8 rows; (ii) a checkpoint whose to_out / ff.net.2
+    biases put a mean of ~30 standard deviations on every row of the residual stream: the folded LayerNorm computes
+    rstd (W' x - mean s), so a large mean is the case in which its subtraction cancels most of the product's bits."""
+    dims = synth.CFM_TINY
+    w = synth.synth_cfm_weights(dims, 777)
+    T, B = 900, 2
+    mu, spks, cond, z = synth.synth_cfm_inputs(dims, T, 9, B)
+    mask = np.ones((B, 1, T), np.float32)
+    mask[1, 0, T - 11:] = 0.0
+    t = np.array([0.2, 0.7], np.float32)
+    want = _oracle(dims, w).forward(z, mask, mu, t, spks, cond)
+    with cb.load_cfm_estimator(synth.ensure_cfm_checkpoint(dims, 777)) as est:
+        got = est.forward(z, mask, mu, t, spks, cond)
+    assert _rel(got, want) < TOL, _rel(got, want)
+    w2 = dict(w)
+    n = 0
+    for k in w:
+        if k.endswith("attn1.to_out.0.bias") or k.endswith("ff.net.2.bias"):
+            w2[k] = (w[k] + np.float32(25.0 if n % 2 == 0 else -18.0)).astype(np.float32)
+            n += 1
+    assert n >= 2 * (dims.n_mid + 2) * dims.n_tfm
+    path = str(tmp_path / "cfm_large_means.safetensors")
+    synth.write_safetensors(w2, path)
+    T = 61
+    mu, spks, cond, z = synth.synth_cfm_inputs(dims, T, 10, 2)
+    mask = np.ones((2, 1, T), np.float32)
+    want = _oracle(dims, w2).forward(z, mask, mu, t, spks, cond)
+    with cb.load_cfm_estimator(path) as est:
+        got = est.forward(z, mask, mu, t, spks, cond)
+    assert _rel(got, want) < TOL, _rel(got, want)
