@@ -8,7 +8,7 @@ libt3mi.so's gfx950 kernels or not at all."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
+from typing import Optional, Sequence
 
 import numpy as np
 
@@ -244,3 +244,66 @@ def s3gen_inference(flow: S3GenFlow, vocoder: HiftVocoder, speech_tokens, ref_di
     if timing is not None:
         timing.update(flow_ms=t_flow.get("device_ms"), vocoder_ms=t_voc.get("device_ms"))
     return audio, mel
+
+
+S3GEN_SIL = 4299      # silence token appended three times on Turbo (R/s3gen.R:6, R/tts.R:374-378)
+
+
+def synthesize(handles, token_lists: Sequence, ref_dict: dict, seed: Optional[int] = None, turbo: bool = False,
+               n_cfm_timesteps: Optional[int] = None, timing: Optional[dict] = None) -> list:
+    """The waveform half of generate() (R/tts.R:365-412) for several utterances of ONE voice: every token vector (already through
+    drop_invalid_tokens) -> s3gen$inference(finalize = TRUE) -> audio samples; an empty vector gives an empty array (the
+    reference warns "No valid speech tokens generated" and returns numeric(0)).  On Turbo three silence tokens are appended and
+    the meanflow solve takes 2 steps (R/tts.R:374-389).
+
+    `handles`: one (flow, vocoder) pair, or a list of pairs -- the utterances are then dealt over the pairs, one host thread per
+    pair (independent launch chains fill each other's gaps: DESIGN.md 3.5; four pairs per GPU measured best; pairs may sit
+    on different GPUs).  The draws the reference takes from torch's generator (CFM start noise, harmonic start phases, source
+    noise) come from numpy generators keyed by (seed, utterance index): the audio of an utterance does not depend on the number
+    of handles.  seed = None draws one from numpy's global RNG, like t3.py's wrappers."""
+    import threading
+
+    pairs = [handles] if isinstance(handles[0], S3GenFlow) else list(handles)
+    if seed is None:
+        seed = int(np.random.randint(0, 2**31 - 1))
+    toks = [np.asarray(t, dtype=np.int64).reshape(-1) for t in token_lists]
+    out: list = [None] * len(toks)
+    times: list = [None] * len(toks)
+    n_prompt = int(np.reshape(ref_dict["prompt_token"], -1).size)
+    steps = n_cfm_timesteps if n_cfm_timesteps is not None else (2 if turbo else None)
+    errors: list = []
+
+    def work(w: int):
+        flow, voc = pairs[w]
+        try:
+            for u in range(w, len(toks), len(pairs)):
+                t = toks[u]
+                if t.size == 0:
+                    out[u] = np.zeros(0, np.float32)
+                    continue
+                if turbo:
+                    t = np.concatenate([t, np.full(3, S3GEN_SIL, t.dtype)])
+                rng = np.random.Generator(np.random.PCG64([int(seed), u]))
+                frames_all = 2 * (n_prompt + t.size)
+                z = rng.standard_normal((1, flow.mel, frames_all), dtype=np.float32)
+                phase = rng.uniform(-np.pi, np.pi, voc.n_harmonics).astype(np.float32)
+                snoise = rng.standard_normal((voc.n_harmonics, 2 * t.size * voc.samples_per_frame), dtype=np.float32)
+                tm: dict = {}
+                out[u], _ = s3gen_inference(flow, voc, t, ref_dict, z, phase, snoise, finalize=True, n_cfm_timesteps=steps, timing=tm)
+                times[u] = tm
+        except Exception as e:  # noqa: BLE001 -- re-raised in the caller's thread
+            errors.append(e)
+
+    if len(pairs) == 1:
+        work(0)
+    else:
+        ts = [threading.Thread(target=work, args=(w,)) for w in range(len(pairs))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    if errors:
+        raise errors[0]
+    if timing is not None:
+        timing["per_utterance"] = times
+    return out

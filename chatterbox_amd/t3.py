@@ -376,7 +376,7 @@ def split_sentences(text: str) -> List[str]:
 
 
 def tts_chunked(model: T3Model, text: str, cond: T3Cond, tokenize, chunk_size: int = 200, batched: bool = True,
-                drop_invalid: bool = True, **kw) -> dict:
+                drop_invalid: bool = True, s3gen=None, ref_dict: Optional[dict] = None, **kw) -> dict:
     """tts_chunked (R/tts.R:455-480) up to the speech tokens: the text is split into sentences exactly as the
     reference does, every sentence is tokenised by `tokenize(sentence) -> text token ids` (the reference's BPE
     tokenizer, or punc_norm + the GPT-2 tokenizer on Turbo: R/tts.R:278-285 -- host string work, out of scope
@@ -389,7 +389,9 @@ def tts_chunked(model: T3Model, text: str, cond: T3Cond, tokenize, chunk_size: i
     and unused, as in the reference.  Keyword arguments are those of t3_inference / t3_inference_turbo
     (generate() passes cfg_weight, temperature, top_p, and top_k / repetition_penalty on Turbo: R/tts.R:303-360).
     Returns {"sentences": [...], "speech_tokens": [array per sentence]} with drop_invalid_tokens applied
-    (R/tts.R:366); the waveform side (S3Gen, R/tts.R:392-412) stays with the reference."""
+    (R/tts.R:366).  With `s3gen` (one (flow, vocoder) pair of chatterbox_amd.s3gen, or a list of pairs) and the voice's
+    `ref_dict` the waveform side runs too (R/tts.R:365-412, s3gen.synthesize): the result then also carries "audio" -- the
+    sentences' samples concatenated, as R/tts.R:474 does -- and "sample_rate" (24000)."""
     sentences = split_sentences(text)
     if not sentences:
         return {"sentences": [], "speech_tokens": []}
@@ -403,7 +405,15 @@ def tts_chunked(model: T3Model, text: str, cond: T3Cond, tokenize, chunk_size: i
         out = fn(model, [cond] * len(sentences), toks, drop_invalid=di, **kw)
     else:
         out = [fn(model, [cond], [t], first_utterance_id=i, drop_invalid=di, **kw)[0] for i, t in enumerate(toks)]
-    return {"sentences": sentences, "speech_tokens": out}
+    res = {"sentences": sentences, "speech_tokens": out}
+    if s3gen is not None:
+        from . import s3gen as _s3
+        if ref_dict is None:
+            raise ValueError("tts_chunked: s3gen needs the voice's ref_dict (prompt_token, prompt_feat, embedding)")
+        wavs = _s3.synthesize(s3gen, out, ref_dict, seed=kw["seed"], turbo=turbo)
+        res["audio"] = np.concatenate(wavs) if wavs else np.zeros(0, np.float32)
+        res["sample_rate"] = _s3.S3GEN_SR
+    return res
 
 
 class Session:

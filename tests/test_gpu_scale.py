@@ -373,3 +373,55 @@ def test_drop_invalid_tokens_on_device():
         assert all(dims.stop_speech_token not in t and (len(t) == 0 or t.max() < dims.start_speech_token) for t in stop)
     finally:
         model.close()
+
+
+def test_tts_chunked_text_to_waveform():
+    """tts_chunked end to end (R/tts.R:455-480 with generate()'s tail, R/tts.R:365-412): sentences -> ONE batched T3 call ->
+    drop_invalid_tokens -> s3gen.synthesize over one and over two (flow, vocoder) pairs -> concatenated samples.  Reduced
+    modules (token ids beyond the flow's table are clamped, R/s3gen.R:833).  The audio equals per-sentence s3gen_inference
+    calls on the same draws, does not depend on the number of handles, and a sentence without valid tokens contributes nothing."""
+    dims, path = _peaked()
+    fd, hd = synth.FLOW_TINY, synth.HIFT_TINY
+    model = cb.load_t3(path, device=0, start_speech_token=dims.start_speech_token, stop_speech_token=dims.stop_speech_token)
+    pairs = [(cb.load_s3gen_flow(synth.ensure_flow_checkpoint(fd, 555)), cb.load_hift_vocoder(synth.ensure_hift_checkpoint(hd, 999))) for _ in range(2)]
+    try:
+        rng = np.random.default_rng(3)
+        cond = cb.t3_cond((rng.standard_normal(dims.speaker_embed) * 0.1).astype(np.float32),
+                          rng.integers(0, dims.start_speech_token, 40), emotion_adv=0.5)
+        _tok, ptok, pfeat, xvec, _z = synth.synth_flow_inputs(fd, 4, 9, 2)
+        ref = dict(prompt_token=ptok, prompt_feat=pfeat, embedding=xvec)
+        text = "The quick brown fox.  It jumps over the dog! Does it?"
+
+        def tokenize(sentence):
+            return [1 + (b % 250) for b in sentence.encode()]
+
+        kw = dict(max_new_tokens=12, seed=11, top_p=0.9, cfg_weight=0.5, temperature=0.8)
+        one = cb.tts_chunked(model, text, cond, tokenize, s3gen=pairs[0], ref_dict=ref, **kw)
+        two = cb.tts_chunked(model, text, cond, tokenize, s3gen=pairs, ref_dict=ref, **kw)
+        assert one["sample_rate"] == 24000 and len(one["speech_tokens"]) == 3
+        n = [len(t) for t in one["speech_tokens"]]
+        assert all(k > 0 for k in n) and one["audio"].size == sum(2 * k * 480 for k in n)
+        assert np.isfinite(one["audio"]).all() and np.abs(one["audio"]).max() <= 0.99 + 1e-6 and np.abs(one["audio"]).max() > 0
+        assert np.array_equal(one["audio"], two["audio"])
+        # by hand: the same draws, sentence by sentence
+        off = 0
+        for u, t in enumerate(one["speech_tokens"]):
+            g = np.random.Generator(np.random.PCG64([11, u]))
+            z = g.standard_normal((1, fd.cfm.mel, 2 * (ptok.size + len(t))), dtype=np.float32)
+            ph = g.uniform(-np.pi, np.pi, hd.n_harm).astype(np.float32)
+            sn = g.standard_normal((hd.n_harm, 2 * len(t) * 480), dtype=np.float32)
+            a, _ = cb.s3gen_inference(pairs[1][0], pairs[1][1], t, ref, z, ph, sn)
+            assert np.array_equal(one["audio"][off:off + a.size], a)
+            assert not a[:480].any()                      # 20 ms of silence, then the fade-in (R/s3gen.R:922-927)
+            off += a.size
+        wavs = cb.synthesize(pairs, [one["speech_tokens"][0], [], one["speech_tokens"][2]], ref, seed=11)
+        assert wavs[1].size == 0 and wavs[0].size == 2 * n[0] * 480
+        tur = cb.synthesize(pairs[0], [one["speech_tokens"][0]], ref, seed=11, turbo=True, n_cfm_timesteps=2)
+        assert tur[0].size == 2 * (n[0] + 3) * 480       # three silence tokens appended (R/tts.R:374-378)
+        with pytest.raises(ValueError):
+            cb.tts_chunked(model, text, cond, tokenize, s3gen=pairs[0], **kw)
+    finally:
+        model.close()
+        for f, v in pairs:
+            f.close()
+            v.close()
