@@ -231,7 +231,8 @@ tts_chunked <- function (model, text, voice, chunk_size = 200, exaggeration = 0.
                          temperature = 0.8, top_p = 0.9, autocast = NULL, traced = FALSE, top_k = 1000L,
                          repetition_penalty = 1.2, seed = NULL, devices = 0L,
                          native = t3mi_model(variant = if (isTRUE(model$turbo)) "turbo" else "llama",
-                                             device = devices[1L]))
+                                             device = devices[1L]),
+                         s3gen_native = NULL)      # t3mi_s3gen() (R/s3gen_native.R): the waveform side on the MI355X as well
 {
     if (!is_loaded(model)) stop("Model not loaded. Call load_chatterbox() first.")
     sentences <- strsplit(text, "(?<=[.!?])\\s+", perl = TRUE)[[1]]
@@ -270,6 +271,11 @@ tts_chunked <- function (model, text, voice, chunk_size = 200, exaggeration = 0.
         vals <- as.integer(tk)
         if (is_turbo) vals <- c(vals, rep(S3GEN_SIL, 3L))
         st <- torch::torch_tensor(vals, dtype = torch::torch_long())$unsqueeze(1L)$to(device = device)
+        if (!is.null(s3gen_native)) {     # no R-torch op between the ids and the samples; draws from R's RNG (set.seed governs)
+            audio <- s3gen_inference_native(st, voice$ref_dict, finalize = TRUE, meanflow = is_turbo, native = s3gen_native)[[1]]
+            all_audio <- c(all_audio, as.numeric(audio$squeeze()$cpu()))
+            next
+        }
         synth <- function ()
             model$s3gen$inference(speech_tokens = st, ref_dict = voice$ref_dict, finalize = TRUE, traced = traced,
                                   n_cfm_timesteps = if (is_turbo) 2L else NULL)[[1]]
