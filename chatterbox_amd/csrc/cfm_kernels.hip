@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 namespace t3k {
 
@@ -410,7 +411,8 @@ int cfm_attn_splits(int n_seq, int T, int heads) {
     // every split at least one 64-key tile
     const long long waves = (long long)((T + 15) / 16) * heads * n_seq;
     const int n_tiles = (T + 63) / 64;
-    int want = (int)((2048 + waves - 1) / waves);
+    static const int target = getenv("T3MI_CFM_ATTN_WAVES") ? atoi(getenv("T3MI_CFM_ATTN_WAVES")) : 2048;   // tuning runs only
+    int want = (int)((target + waves - 1) / waves);
     want = want < 1 ? 1 : (want > kCfmAttnMaxSplit ? kCfmAttnMaxSplit : want);
     want = want > n_tiles ? n_tiles : want;
     const int tps = (n_tiles + want - 1) / want;
