@@ -125,7 +125,7 @@ SYMBOLS = {
     "t3mi_hift_open": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_H)]),
     "t3mi_hift_close": (C.c_int, [_H]),
     "t3mi_hift_get_info": (C.c_int, [_H, C.POINTER(HiftInfo)]),
-    "t3mi_hift_inference": (C.c_int, [_H, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP, _FP]),
+    "t3mi_hift_inference": (C.c_int, [_H, C.c_int, _FP, _FP, _FP, _FP, C.c_int, _FP, _FP, _FP, _FP]),
     "t3mi_cfm_solve": (C.c_int, [_H, C.c_int, _FP, _FP, _FP, _FP, _FP, C.c_int, C.c_double, C.c_int, _FP, _FP]),
 }
 

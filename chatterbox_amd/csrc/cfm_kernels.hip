@@ -131,13 +131,16 @@ __global__ __launch_bounds__(64 * NW) void cfm_attn_kernel(const float* __restri
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);      // finite from the first tile on (a split's first tile holds a valid key)
-        const float alpha = expf(m_run - m_new);
+        // the hardware exponential (v_exp_f32 on x log2 e, about 1 ulp): libm's expf is ~20 VALU instructions, 16 of them per lane
+        // and tile sat between the two MFMA phases (15.9 -> 14.9 us per launch at T = 500); probabilities are summed and
+        // normalised, the bar is 1e-3 of the output's magnitude
+        const float alpha = __expf(m_run - m_new);
         float ls = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = expf(s[kt][r] - m_new);
+                const float p = __expf(s[kt][r] - m_new);
                 s[kt][r] = p;
                 ls += p;
             }

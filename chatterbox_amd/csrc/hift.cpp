@@ -380,11 +380,13 @@ int t3mi_hift_get_info(const t3mi_hift* m, t3mi_hift_info* info) {
     return T3MI_OK;
 }
 
-int t3mi_hift_inference(t3mi_hift* m, int T, const float* mel, const float* phase, const float* noise, float* audio, float* source_out,
-                        float* f0_out, float* device_ms) {
+int t3mi_hift_inference(t3mi_hift* m, int T, const float* mel, const float* phase, const float* noise, const float* cache_source,
+                        int cache_len, float* audio, float* source_out, float* f0_out, float* device_ms) {
     if (!m) return fail(T3MI_ERR_ARG, "null HiFT handle");
     if (!mel || !audio) return fail(T3MI_ERR_ARG, "t3mi_hift_inference: null argument");
     if (T < 2 || T > (1 << 15)) return fail(T3MI_ERR_ARG, "t3mi_hift_inference: the mel must hold 2 .. 32768 frames");
+    if (cache_len < 0 || (cache_len > 0 && !cache_source) || (long long)cache_len > (long long)T * kTotalUp)
+        return fail(T3MI_ERR_ARG, "t3mi_hift_inference: cache_source must hold cache_len <= 480 T samples");
     HIPCHK(hipSetDevice(m->device));
     int rc = ensure_ws(m, T);
     if (rc) return rc;
@@ -432,6 +434,8 @@ int t3mi_hift_inference(t3mi_hift* m, int T, const float* mel, const float* phas
     // ---- f0_upsamp + m_source (R/hifigan.R:609-614) ----
     HSTEP(t3k::launch_hift_source(m->f0v.f(), static_cast<double*>(m->base_d.p), m->phase.f(), noise ? m->noise.f() : nullptr, m->src_lw,
                                   m->src_lb, T, m->n_harm, kTotalUp, kSr, kVoiced, m->src.f(), st));
+    if (cache_len > 0)   // s[,, 1:cache_len] <- cache_source (R/hifigan.R:617-620)
+        HSTEP(hipMemcpyAsync(m->src.p, cache_source, (size_t)cache_len * 4, hipMemcpyHostToDevice, st));
     // ---- decode (R/hifigan.R:503-578) ----
     HSTEP(t3k::launch_hift_stft(m->src.f(), Tw, m->stft.f(), kSpecLd, st));
     {

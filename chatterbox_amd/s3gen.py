@@ -173,10 +173,11 @@ class HiftVocoder:
         self.info = info
         self.mel, self.n_harmonics, self.samples_per_frame = int(info.mel), int(info.n_harmonics), int(info.samples_per_frame)
 
-    def inference(self, speech_feat, phase=None, noise=None, timing: Optional[dict] = None) -> dict:
+    def inference(self, speech_feat, phase=None, noise=None, timing: Optional[dict] = None, cache_source=None) -> dict:
         """hift_generator$inference(speech_feat) (R/hifigan.R:601-626): speech_feat (1, mel, T) or (mel, T) -> {"audio": [480 T],
         "source": [480 T], "f0": [T]}.  phase [n_harmonics] / noise [n_harmonics, 480 T]: the draws the reference takes from
-        torch's generator (R/hifigan.R:237-249); None = zero phases / no noise term."""
+        torch's generator (R/hifigan.R:237-249); None = zero phases / no noise term.  cache_source [n <= 480 T]: the previous
+        chunk's source tail, written over the start of this call's source (R/hifigan.R:617-620)."""
         m = _f32(speech_feat)
         if m.ndim == 3:
             m = m[0]
@@ -189,7 +190,9 @@ class HiftVocoder:
         nz = None if noise is None else _f32(noise, (self.n_harmonics, n))
         audio, src, f0 = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(T, np.float32)
         ms = C.c_float(0)
-        _lib.check(self._lib.t3mi_hift_inference(self._h, T, _p(m), _p(ph), _p(nz), _p(audio), _p(src), _p(f0), C.byref(ms)))
+        cs = None if cache_source is None else _f32(np.reshape(cache_source, -1))
+        _lib.check(self._lib.t3mi_hift_inference(self._h, T, _p(m), _p(ph), _p(nz), _p(cs), 0 if cs is None else int(cs.size), _p(audio),
+                                                 _p(src), _p(f0), C.byref(ms)))
         if timing is not None:
             timing["device_ms"] = float(ms.value)
         return {"audio": audio, "source": src, "f0": f0}

@@ -306,14 +306,16 @@ typedef struct t3mi_hift_info {
 int t3mi_hift_open(const char* safetensors_path, const char* prefix, int device, t3mi_hift** out);
 int t3mi_hift_close(t3mi_hift* m);
 int t3mi_hift_get_info(const t3mi_hift* m, t3mi_hift_info* info);
-/* hift_generator$inference(speech_feat) without a source cache (R/hifigan.R:601-626): mel (80, T) -> audio [480 T], clamped
+/* hift_generator$inference(speech_feat, cache_source) (R/hifigan.R:601-626): mel (80, T) -> audio [480 T], clamped
  * to +-0.99 (:577).  The reference draws the harmonics' start phases (uniform(-pi, pi), entry 0 forced to 0) and the source
  * noise (standard normal, [n_harmonics][480 T]) from torch's generator (:237-249): here the caller hands them in (phase NULL:
  * zeros; noise NULL: no noise term).  source_out [480 T] and f0_out [T] (either may be NULL) return the source signal and the
- * predicted F0 (the list elements `source` / `f0` of the reference's result).  s3gen$inference then applies its 20 ms fade-in
+ * predicted F0 (the list elements `source` / `f0` of the reference's result).  cache_source [cache_len] (NULL / 0: none): the
+ * source of the previous chunk's tail, written over the first cache_len samples of this call's source before decoding
+ * (s[,, 1:cache_len] <- cache_source, :617-620; cache_len <= 480 T).  s3gen$inference then applies its 20 ms fade-in
  * (R/s3gen.R:1047-1049), which stays with the caller.  device_ms (may be NULL): HIP-event time of the pass. */
-int t3mi_hift_inference(t3mi_hift* m, int T, const float* mel, const float* phase, const float* noise, float* audio, float* source_out,
-                        float* f0_out, float* device_ms);
+int t3mi_hift_inference(t3mi_hift* m, int T, const float* mel, const float* phase, const float* noise, const float* cache_source,
+                        int cache_len, float* audio, float* source_out, float* f0_out, float* device_ms);
 
 #ifdef __cplusplus
 }

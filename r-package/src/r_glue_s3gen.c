@@ -107,7 +107,7 @@ SEXP t3mi_r_hift_inference(SEXP voc, SEXP mel, SEXP n_frames, SEXP phase, SEXP n
     float* nz = noise == R_NilValue ? NULL : to_float(noise, n * hi.n_harmonics);
     float* audio = (float*)malloc((size_t)(n > 0 ? n : 1) * sizeof(float));
     const int bad_args = !ml || !audio || (phase != R_NilValue && !ph) || (noise != R_NilValue && !nz);
-    int rc = bad_args ? T3MI_ERR_ARG : t3mi_hift_inference(m, T, ml, ph, nz, audio, NULL, NULL, NULL);
+    int rc = bad_args ? T3MI_ERR_ARG : t3mi_hift_inference(m, T, ml, ph, nz, NULL, 0, audio, NULL, NULL, NULL);
     free(ml); free(ph); free(nz);
     if (rc < 0) {
         free(audio);

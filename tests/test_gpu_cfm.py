@@ -246,6 +246,16 @@ def test_hift_without_noise_or_phase_and_bad_input():
         with pytest.raises(_lib.T3miError) as e:
             voc.inference(mel[:, :1])
         assert e.value.code == _lib.ERR_ARG
+        # cache_source (R/hifigan.R:617-620): the previous chunk's source tail replaces the start of this call's source
+        cache = np.random.default_rng(4).uniform(-0.5, 0.5, 700).astype(np.float32)
+        full = voc.inference(mel, phase, noise)
+        cached = voc.inference(mel, phase, noise, cache_source=cache)
+        assert np.array_equal(cached["source"][:700], cache) and np.array_equal(cached["source"][700:], full["source"][700:])
+        assert np.abs(cached["audio"] - orc.decode(mel, cached["source"])).max() < TOL
+        assert not np.array_equal(cached["audio"][:700], full["audio"][:700])
+        with pytest.raises(_lib.T3miError) as e:
+            voc.inference(mel, phase, noise, cache_source=np.zeros(9 * 480 + 1, np.float32))
+        assert e.value.code == _lib.ERR_ARG
     with pytest.raises(_lib.T3miError) as e:
         cb.load_hift_vocoder(synth.ensure_cfm_checkpoint(synth.CFM_TINY, 777))
     assert e.value.code == _lib.ERR_IO
