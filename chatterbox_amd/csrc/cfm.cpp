@@ -652,6 +652,30 @@ int encoder_rows(t3mi_cfm* m, int T) {
     return T3MI_OK;   // result in xn [2T][d]
 }
 
+// a pair of timing events that cannot leak on an early return
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    EventPair() = default;
+    EventPair(const EventPair&) = delete;
+    EventPair& operator=(const EventPair&) = delete;
+    ~EventPair() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    hipError_t start(hipStream_t st) {
+        hipError_t e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) e = hipEventRecord(e0, st);
+        return e;
+    }
+    hipError_t stop(hipStream_t st, float* ms) {
+        hipError_t e = hipEventRecord(e1, st);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1);
+        return e;
+    }
+};
+
 int check_handle(t3mi_cfm* m) {
     if (!m) return fail(T3MI_ERR_ARG, "null CFM handle");
     return T3MI_OK;
@@ -738,7 +762,7 @@ int t3mi_cfm_solve(t3mi_cfm* m, int T, const float* z, const float* mu, const fl
     int rc = check_handle(m);
     if (rc) return rc;
     if (!z || !mu || !mask || !spks || !cond || !out) return fail(T3MI_ERR_ARG, "t3mi_cfm_solve: null argument");
-    if (T <= 0 || T > (1 << 20)) return fail(T3MI_ERR_ARG, "t3mi_cfm_solve: bad sequence length");
+    if (T <= 0 || T > (1 << 16)) return fail(T3MI_ERR_ARG, "t3mi_cfm_solve: the sequence must hold 1 .. 65536 mel frames");
     if (n_timesteps <= 0 || n_timesteps > 1000) return fail(T3MI_ERR_ARG, "t3mi_cfm_solve: n_timesteps must be in 1..1000");
     if (meanflow && !m->meanflow) return fail(T3MI_ERR_ARG, "t3mi_cfm_solve: meanflow asked of a checkpoint without time_embed_mixer");
     HIPCHK(hipSetDevice(m->device));
@@ -781,12 +805,8 @@ int t3mi_cfm_solve(t3mi_cfm* m, int T, const float* z, const float* mu, const fl
     HIPCHK(hipMemcpyAsync(m->stat.p, stat.data(), stat.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(m->mask.p, mk.data(), mk.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(m->ttab.p, ttab.data(), ttab.size() * 4, hipMemcpyHostToDevice, st));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (device_ms) {
-        HIPCHK(hipEventCreate(&e0));
-        HIPCHK(hipEventCreate(&e1));
-        HIPCHK(hipEventRecord(e0, st));
-    }
+    EventPair ev;
+    if (device_ms) HIPCHK(ev.start(st));
     const float rate = (float)cfg_rate, one_plus = (float)(1.0 + cfg_rate);
     for (int s = 0; s < n && !rc; ++s) {
         hipError_t e = hipMemcpyAsync(m->tcur.p, m->ttab.f() + (size_t)s * 2 * B, (size_t)2 * B * 4, hipMemcpyDeviceToDevice, st);
@@ -800,13 +820,9 @@ int t3mi_cfm_solve(t3mi_cfm* m, int T, const float* z, const float* mu, const fl
         if (e != hipSuccess) rc = fail(T3MI_ERR_HIP, std::string("t3mi_cfm_solve: ") + hipGetErrorString(e));
     }
     if (device_ms && !rc) {
-        hipError_t e = hipEventRecord(e1, st);
-        if (e == hipSuccess) e = hipEventSynchronize(e1);
-        if (e == hipSuccess) e = hipEventElapsedTime(device_ms, e0, e1);
+        hipError_t e = ev.stop(st, device_ms);
         if (e != hipSuccess) rc = fail(T3MI_ERR_HIP, std::string("t3mi_cfm_solve: event timing: ") + hipGetErrorString(e));
     }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
     if (rc) {
         (void)hipStreamSynchronize(st);
         return rc;
@@ -879,14 +895,18 @@ int t3mi_flow_inference(t3mi_cfm* m, const int32_t* token, int n_token, const in
     HIPCHK(hipSetDevice(m->device));
     Flow* f = m->flow.get();
     const int T = n_prompt + n_token, mel = m->mel;
+    int T2 = 2 * T;
+    if (!finalize) T2 -= 3 * 2;                                                                    // pre_lookahead_len * token_mel_ratio, :844-846
+    const int mel_len1 = 2 * n_prompt, mel_len2 = T2 - mel_len1;
+    if (mel_len2 <= 0) return fail(T3MI_ERR_ARG, "t3mi_flow_inference: nothing left to generate after the prompt");
+    if (cap_frames < mel_len2) return fail(T3MI_ERR_ARG, "t3mi_flow_inference: output holds fewer than " + std::to_string(mel_len2) + " frames");
+    if (noise_T < T2) return fail(T3MI_ERR_ARG, "t3mi_flow_inference: the noise must cover " + std::to_string(T2) + " frames");
+    if (n_timesteps <= 0 || n_timesteps > 1000) return fail(T3MI_ERR_ARG, "t3mi_flow_inference: n_timesteps must be in 1..1000");
+    if (meanflow && !m->meanflow) return fail(T3MI_ERR_ARG, "t3mi_flow_inference: meanflow asked of a checkpoint without time_embed_mixer");
     if ((rc = flow_ws(m, T))) return rc;
     hipStream_t st = m->stream;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (device_ms) {
-        HIPCHK(hipEventCreate(&e0));
-        HIPCHK(hipEventCreate(&e1));
-        HIPCHK(hipEventRecord(e0, st));
-    }
+    EventPair ev;
+    if (device_ms) HIPCHK(ev.start(st));
     // token <- cat(prompt_token, token), clamped to the table (R/s3gen.R:826-836; the mask is all ones for one utterance)
     std::vector<int32_t> ids((size_t)T);
     for (int i = 0; i < T; ++i) {
@@ -905,26 +925,14 @@ int t3mi_flow_inference(t3mi_cfm* m, const int32_t* token, int n_token, const in
     HIPCHK(hipMemcpyAsync(f->spk_in.p, en.data(), en.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(t3k::launch_embed_rows(f->embedding, static_cast<const int*>(f->ids.p), nullptr, f->x0.f(), T, f->d, st));
     if ((rc = encoder_rows(m, T))) return rc;                                                      // :839
-    int T2 = 2 * T;
-    if (!finalize) T2 -= 3 * 2;                                                                    // pre_lookahead_len * token_mel_ratio, :844-846
-    const int mel_len1 = 2 * n_prompt, mel_len2 = T2 - mel_len1;
-    if (mel_len2 <= 0) return fail(T3MI_ERR_ARG, "t3mi_flow_inference: nothing left to generate after the prompt");
-    if (cap_frames < mel_len2) return fail(T3MI_ERR_ARG, "t3mi_flow_inference: output holds fewer than " + std::to_string(mel_len2) + " frames");
-    if (noise_T < T2) return fail(T3MI_ERR_ARG, "t3mi_flow_inference: the noise must cover " + std::to_string(T2) + " frames");
     if ((rc = fgemm(m, f->xn.f(), f->enc_proj, T2, t3k::EPI_STORE, f->mu.f(), nullptr))) return rc;   // encoder_proj, :854
     if ((rc = fgemm(m, f->spk_in.f(), f->spk_affine, 1, t3k::EPI_STORE, f->spk_out.f(), nullptr))) return rc;
     std::vector<float> mu_rows((size_t)T2 * mel), spk((size_t)mel);
     HIPCHK(hipMemcpyAsync(mu_rows.data(), f->mu.p, mu_rows.size() * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(spk.data(), f->spk_out.p, spk.size() * 4, hipMemcpyDeviceToHost, st));
     float enc_ms = 0.f;
-    if (device_ms) {
-        HIPCHK(hipEventRecord(e1, st));
-        HIPCHK(hipEventSynchronize(e1));
-        HIPCHK(hipEventElapsedTime(&enc_ms, e0, e1));
-    }
+    if (device_ms) HIPCHK(ev.stop(st, &enc_ms));
     HIPCHK(hipStreamSynchronize(st));
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
     // decoder inputs in the reference's layouts (R/s3gen.R:857-883): mu (1, mel, T2); conds = the prompt mel over its frames
     std::vector<float> mu((size_t)mel * T2), cond((size_t)mel * T2, 0.f), mask((size_t)T2, 1.0f), z((size_t)mel * T2), res((size_t)mel * T2);
     const int nc = std::min(n_feat, mel_len1);
