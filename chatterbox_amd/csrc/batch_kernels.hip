@@ -447,7 +447,29 @@ template <typename KVT> __device__ __forceinline__ float attn_exp(float v) {
     else return expf(v);
 }
 
-template <typename KVT, typename OT, int NW>   // NW waves per block
+// PfArgs (kernels.hpp): prefetch block p of a launch whose blocks have nthr threads
+__device__ __forceinline__ void prefetch_block(const PfArgs& f, unsigned p, unsigned nthr) {
+    unsigned acc = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const char* base = static_cast<const char*>(f.ptr[r]);
+        if (f.unit[r] == 0) {
+            const unsigned lines = f.bytes[r] >> 7;
+            for (unsigned i = p * nthr + threadIdx.x; i < lines; i += (unsigned)f.n_blocks * nthr) acc ^= *reinterpret_cast<const unsigned*>(base + ((size_t)i << 7));
+        } else {
+            const unsigned xcd = p & 7u, pi = p >> 3, npx = (unsigned)f.n_blocks >> 3;   // this XCD's prefetch blocks
+            const unsigned lpu = f.unit[r] >> 7, units = f.bytes[r] / f.unit[r], upx = units >> 3;
+            const unsigned share = upx * lpu;
+            for (unsigned i = pi * nthr + threadIdx.x; i < share; i += npx * nthr) {
+                const unsigned k = i / lpu, u = f.remap[r] ? xcd * upx + k : 8u * k + xcd;
+                acc ^= *reinterpret_cast<const unsigned*>(base + (size_t)u * f.unit[r] + ((size_t)(i - k * lpu) << 7));
+            }
+        }
+    }
+    f.sink[(size_t)p * nthr + threadIdx.x] = acc;
+}
+
+template <typename KVT, typename OT, int NW, bool PF = false>   // NW waves per block; PF: grid rows y >= 1 are prefetch blocks (PfArgs)
 __global__ __launch_bounds__(64 * NW, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_kernel(AttnRowsArgs a) {   // bf16 cache: 4 waves per SIMD (128 VGPRs)
     constexpr int NS = NW * 8;   // key streams of the block: (wave, key group)
 
@@ -455,6 +477,12 @@ __global__ __launch_bounds__(64 * NW, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_k
     __shared__ __attribute__((aligned(16))) float sm_acc[NS][kHeadDim + 4];
     // flat grid: block = qi * H + h (the heads of an item are adjacent, as they are in the cache); a 2-D grid with the
     // items in y is capped at 65535 items, which a prefill of a few hundred prompts exceeds
+    if constexpr (PF) {
+        if (blockIdx.y != 0) {   // (block-uniform)
+            prefetch_block(a.pf, (blockIdx.y - 1) * gridDim.x + blockIdx.x, 64 * NW);
+            return;
+        }
+    }
     const int h = (int)(blockIdx.x % (unsigned)a.n_heads), qi = (int)(blockIdx.x / (unsigned)a.n_heads);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kg = lane >> 3, dc = lane & 7;
@@ -1106,7 +1134,7 @@ constexpr int kAsRedStride = 20;   // floats per (row) of the reduction buffer: 
 // tests in the common kernel every launch measured 2 % slower.  (A first LayerNorm form computed the products activation row x
 // column means inside this kernel, from the staging registers: 8 more 16-byte loads per thread, o_proj 6.1 us at 8 rows against
 // 4.3 for the K-split LDS-staged kernel; the attention launch has each head's 64 values in registers anyway.)
-template <int EPI, typename T, int NSUB, int KB, int MC, int NRM = 0>
+template <int EPI, typename T, int NSUB, int KB, int MC, int NRM = 0, bool PF = false>
 __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte piece: 8 (bf16) or 4 (fp32)
     constexpr int KS = 4 * E;                // k per step (64 B of a row): 32 or 16
@@ -1128,6 +1156,12 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     const int sub = wave % NSUB, kw = wave / NSUB;
     const int m0 = blockIdx.y * MC, kz = blockIdx.z;
     const int K = a.K;
+    if constexpr (PF) {   // grid rows y >= 1 are prefetch blocks (PfArgs); the GEMM itself has one row chunk
+        if (blockIdx.y != 0) {   // (block-uniform)
+            prefetch_block(a.pf, (blockIdx.y - 1) * gridDim.x + blockIdx.x, 512);
+            return;
+        }
+    }
     T3K_DBG_DECL(a.dbg != nullptr && tid == 0, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
     T3K_DBG_STAMP(0);
     // Every global load of the kernel is issued here, activations first: they come from L2 and are consumed first, and
@@ -1451,7 +1485,27 @@ hipError_t launch_gemm_as_v(const GemmArgs& a, int tiles32, int gz, hipStream_t 
         if (e0 != hipSuccess) return e0;
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
-    const dim3 grid((2 * tiles32 + NSUB - 1) / NSUB, (a.M + MC - 1) / MC, gz);
+    dim3 grid((2 * tiles32 + NSUB - 1) / NSUB, (a.M + MC - 1) / MC, gz);
+    if constexpr (MC == 16 && NSUB == 2 && sizeof(T) == 2) {   // (the shapes of the few-row regime the prefetch is for)
+        // prefetch blocks ride as further grid rows of a launch with one row chunk and K unsplit whose width is a multiple of 8
+        if (a.pf.n_blocks > 0 && a.pf.sink != nullptr && grid.y == 1 && grid.z == 1 && (grid.x & 7) == 0) {
+            static bool attr_pf[64] = {};
+            if (dev < 0 || dev >= 64 || !attr_pf[dev]) {
+                hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_as_kernel<EPI, T, NSUB, KB, MC, NRM, true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e0 != hipSuccess) return e0;
+                if (dev >= 0 && dev < 64) attr_pf[dev] = true;
+            }
+            GemmArgs b = a;
+            const unsigned rows = ((unsigned)a.pf.n_blocks + grid.x - 1) / grid.x;
+            b.pf.n_blocks = (int)(rows * grid.x);   // whole rows (the sink holds kPfMaxBlocks blocks)
+            if (b.pf.n_blocks <= kPfMaxBlocks) {
+                grid.y = 1 + rows;
+                hipLaunchKernelGGL((gemm_as_kernel<EPI, T, NSUB, KB, MC, NRM, true>), grid, dim3(512), lds, s, b, tiles32);
+                return hipGetLastError();
+            }
+        }
+    }
     hipLaunchKernelGGL((gemm_as_kernel<EPI, T, NSUB, KB, MC, NRM>), grid, dim3(512), lds, s, a, tiles32);
     return hipGetLastError();
 }
@@ -1795,6 +1849,16 @@ hipError_t launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
     const dim3 block(256);
+    if (a.pf.n_blocks > 0 && a.pf.sink != nullptr && (grid.x & 7) == 0 && a.kv_bf16 && a.out_bf16) {
+        // few (item, head) blocks (this branch: fewer than 256): further grid rows prefetch the next launches' weights (PfArgs)
+        AttnRowsArgs b = a;
+        const unsigned rows = ((unsigned)a.pf.n_blocks + grid.x - 1) / grid.x;
+        b.pf.n_blocks = (int)(rows * grid.x);
+        if (b.pf.n_blocks <= kPfMaxBlocks) {
+            hipLaunchKernelGGL((attn_rows_kernel<uint16_t, uint16_t, 4, true>), dim3(grid.x, 1 + rows), block, 0, s, b);
+            return hipGetLastError();
+        }
+    }
     if (a.kv_bf16 && a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, uint16_t, 4>), grid, block, 0, s, a);
     else if (a.kv_bf16) hipLaunchKernelGGL((attn_rows_kernel<uint16_t, float, 4>), grid, block, 0, s, a);
     else if (a.out_bf16) hipLaunchKernelGGL((attn_rows_kernel<float, uint16_t, 4>), grid, block, 0, s, a);

@@ -74,6 +74,27 @@ struct AttnArgs {
 };
 
 // many-row regime (batched decode, prefill): skinny GEMM on the matrix cores, see batch_kernels.hip
+// Weight prefetch from a launch's idle CUs.  A decode step at few rows is a chain of launches that each leave most of the chip idle
+// and each wait for their weights' first bytes from HBM; n_blocks EXTRA blocks appended to a launch request one dword per 128-byte
+// line of up to two matrices that LATER launches stream, so that those find them in L2.  XCD-aware (what makes it work: hits
+// in the Infinity Cache alone gain nothing): region i is a sequence of units of unit[i] bytes -- the weight range one block
+// column of the consuming activation-stationary GEMM reads -- whose block column u runs on XCD u % 8 (remap[i] = 0) or on XCD
+// u / (units / 8) (1: the split norm's producer); the prefetch blocks are further ROWS of the launch's grid (blockIdx.y >= 1: known
+// without reading a kernel argument -- a test on an argument in front of the kernel's first loads cost every launch 0.2 us), each
+// row as wide as the launch's own (a multiple of 8), so prefetch block p sits on XCD p % 8 and touches only the units its XCD's
+// L2 will be asked for.  unit[i] = 0: no mapping, lines dealt over all blocks.  Every
+// prefetch thread leaves the xor of the words it touched in sink [n_blocks * block size] (a buffer of its own, never read: the
+// store is what keeps the loads in the program).
+constexpr int kPfMaxBlocks = 1024;   // prefetch blocks of one launch (the sink buffer holds 512 words for each)
+struct PfArgs {
+    const void* ptr[2] = {nullptr, nullptr};
+    unsigned bytes[2] = {0, 0};
+    unsigned unit[2] = {0, 0};
+    int remap[2] = {0, 0};
+    int n_blocks = 0;
+    unsigned* sink = nullptr;
+};
+
 struct GemmArgs {
     const void* W = nullptr;      // [N, K] row-major, fp32 or bf16
     const void* Wf = nullptr;     // the same matrix fragment-major (launch_weight_fragments with this launch's epilogue and type), or nullptr
@@ -120,6 +141,7 @@ struct GemmArgs {
     int* ks_out = nullptr;        // host: receives the K-split factor; with it set a residual GEMM in place (y == resid)
                                   // leaves the fold of its partial slabs to the caller (launch_*norm_rows / launch_fold_partials)
     unsigned long long* dbg = nullptr;  // diagnostic builds (-DT3K_STAMPS; scripts/micro/gemm_micro.cpp): [block][4] clock stamps; ignored otherwise
+    PfArgs pf;                    // activation-stationary kernel, one row chunk, K unsplit: see PfArgs (last: the other offsets stay)
 };
 
 struct EmbedArgs {                // token-by-token prefill input (R/t3.R:494, :505)
@@ -208,6 +230,7 @@ struct AttnRowsArgs {
     int M = 0, n_heads = 0, max_len = 0, kv_bf16 = 0, out_bf16 = 0;
     const float* dot_vec = nullptr; // [H*64] and dot_out [M][H], both or neither: dot_out[m][h] = the stored values of head h . dot_vec's
     float* dot_out = nullptr;       // slice of head h (GemmArgs::row_dot of the o_proj launch that follows)
+    PfArgs pf;                      // weight prefetch from the launch's idle CUs (few (item, head) blocks)
 };
 hipError_t launch_attn_rows(const AttnRowsArgs& a, hipStream_t s);
 hipError_t launch_gather_rows(const float* const* src_rows, float* x, int M, int d, hipStream_t s);
