@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     const int sub = wave % NSUB, kw = wave / NSUB;
     const int m0 = blockIdx.y * MC, kz = blockIdx.z;
     const int K = a.K;
-    if constexpr (PF) {   // grid rows y >= 1 are prefetch blocks (PfArgs); the GEMM itself has one row chunk
+    if constexpr (PF) {   // grid rows y >= 1 are prefetch blocks (PfArgs); the GEMM itself has one row chunk and K unsplit
         if (blockIdx.y != 0) {   // (block-uniform)
             prefetch_block(a.pf, (blockIdx.y - 1) * gridDim.x + blockIdx.x, 512);
             return;
@@ -1486,9 +1486,12 @@ hipError_t launch_gemm_as_v(const GemmArgs& a, int tiles32, int gz, hipStream_t 
         if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     dim3 grid((2 * tiles32 + NSUB - 1) / NSUB, (a.M + MC - 1) / MC, gz);
-    if constexpr (MC == 16 && NSUB == 2 && sizeof(T) == 2) {   // (the shapes of the few-row regime the prefetch is for)
-        // prefetch blocks ride as further grid rows of a launch with one row chunk and K unsplit whose width is a multiple of 8
-        if (a.pf.n_blocks > 0 && a.pf.sink != nullptr && grid.y == 1 && grid.z == 1 && (grid.x & 7) == 0) {
+    if constexpr (sizeof(T) == 2 && MC == 16) {   // (bf16, one chunk of up to 16 rows: the regime the prefetch is for)
+        // Prefetch blocks ride as further grid ROWS of a launch with one row chunk and K unsplit whose width is a multiple of 8 (block
+        // -> XCD stays x % 8).  Rows, not layers: with the same blocks placed at z >= 1 the consumers found nothing in their L2s (Llama,
+        // 4 utterances: 0.842 ms per step against 0.825) -- the dispatcher does not deal the blocks of further z layers over the XCDs
+        // the way it deals those of further rows.
+        if (a.pf.n_blocks > 0 && a.pf.sink != nullptr && grid.z == 1 && grid.y == 1 && (grid.x & 7) == 0) {
             static bool attr_pf[64] = {};
             if (dev < 0 || dev >= 64 || !attr_pf[dev]) {
                 hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_as_kernel<EPI, T, NSUB, KB, MC, NRM, true>),
@@ -1521,6 +1524,8 @@ constexpr int kAsMinBlocks = 192;   // sub-tiles per block and K range per block
 // 3.807, the LDS-staged kernel 3.603).
 template <typename T>
 inline int as_chunk_rows(int M) { return M <= 32 ? 16 : 32; }
+// 4 sub-tiles per block when that still leaves kAsMinBlocks blocks, else 2
+inline bool as_four(int tiles32, int chunks, int gz) { return (long long)((2 * tiles32 + 3) / 4) * chunks * gz >= kAsMinBlocks; }
 
 template <int EPI, typename T, int NSUB, int KB>
 hipError_t launch_gemm_as_m(const GemmArgs& a, int tiles32, int gz, hipStream_t s) {
@@ -1567,7 +1572,7 @@ hipError_t launch_gemm_as(const GemmArgs& a, hipStream_t s, bool& handled) {
     if ((a.row_dot != nullptr) != (a.resid_mean != nullptr) || (a.row_dot != nullptr && (a.next_act == nullptr || a.row_dot_n < 1 || a.row_dot_n > 32)))
         return hipSuccess;
     if (a.row_ss != nullptr && ((EPI != EPI_SWIGLU && EPI != EPI_GELU) || a.row_ss_tiles < 1 || a.row_ss_tiles > 32)) return hipSuccess;
-    const bool four = (long long)((2 * tiles32 + 3) / 4) * chunks * gz >= kAsMinBlocks;
+    const bool four = as_four(tiles32, chunks, gz);
     handled = true;
     hipError_t e;
     if (KB == 1024) e = four ? launch_gemm_as_m<EPI, T, 4, 1024>(a, tiles32, gz, s) : launch_gemm_as_m<EPI, T, 2, 1024>(a, tiles32, gz, s);
@@ -1693,6 +1698,26 @@ hipError_t launch_gemm_g(const GemmArgs& a, int epi, hipStream_t s) {
 }
 
 }  // namespace
+
+// Sub-tiles (16 features) per block column of the activation-stationary launch of this shape (bf16 operands), and its K layers:
+// what a prefetch for that launch needs to know (PfArgs::unit).  Mirrors launch_gemm_as.
+int gemm_as_plan(int M, int N, int K, int epilogue, bool splittable, int* gz_out) {
+    const int mc = as_chunk_rows<uint16_t>(M), chunks = (M + mc - 1) / mc;
+    int tiles32;
+    if (epilogue == EPI_ROPE_KV) tiles32 = (N / kHeadDim) * 2;
+    else if (epilogue == EPI_SWIGLU) tiles32 = N / 32;
+    else tiles32 = (N + 31) / 32;
+    int KB = 0;
+    if (K == 1024 || K == 512) KB = K;
+    else if (splittable && K % 1024 == 0) {
+        KB = 1024;
+        if ((long long)tiles32 * chunks * (K / 1024) < kAsMinBlocks && K / 512 <= 8) KB = 512;
+    }
+    if (KB == 0) return 0;
+    const int gz = K / KB;
+    if (gz_out) *gz_out = gz;
+    return as_four(tiles32, chunks, gz) ? 4 : 2;
+}
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t s) {
     if (!a.W || !a.A || a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;

@@ -200,6 +200,9 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t s);
 hipError_t launch_prefill_embed(const EmbedArgs& a, hipStream_t s);
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t s);
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int wdtype, hipStream_t s);
+// 16-feature sub-tiles per block column (2 or 4; 0: not an activation-stationary shape) and K layers of the activation-stationary
+// launch of this shape with bf16 operands: what a prefetch for that launch has to know (PfArgs::unit)
+int gemm_as_plan(int M, int N, int K, int epilogue, bool splittable, int* gz_out);
 // Fragment-major copy of a matrix W [N, K] (wdtype 0 fp32 / 1 bf16) for the activation-stationary GEMM (<= kAsMaxRows
 // rows; GemmArgs::Wf): per 16-feature sub-tile (in the partner order of `epilogue`) and 64-byte k-step, the 64 x 16 B of
 // one MFMA operand.  weight_fragment_elems = elements of the copy (N rounded up to whole 32-feature tiles).

@@ -187,7 +187,7 @@ struct t3mi_model {
     // it runs, and which of {o_proj, gate_up, down, next qkv} are fetched
     // Defaults from the sweep in profiles/r03_weight_prefetch_ab.txt (Turbo, 8 sentences: 0.768 -> 0.732 ms per step; Llama, 4 utterances:
     // 0.878 -> 0.827); T3MI_PF=0 turns it off.  Runs when the attention launch has at most pf_max_blocks (item, head) blocks.
-    int pf_blocks = 128, pf_gblocks = 128, pf_max_blocks = 128, pf_mask = 15, pf_xcd = 1;   // blocks on the attention launch / on a GEMM launch
+    int pf_blocks = 128, pf_gblocks = 128, pf_max_blocks = 128, pf_mask = 31, pf_xcd = 1, pf_max_rows = 16;   // blocks on the attention launch / on a GEMM launch
     DevBuf pf_sink;   // [max(pf_blocks, pf_gblocks) * 512] words the prefetch threads leave their xor in
     int rope_len = 0;
     std::vector<LayerW> layers;
@@ -765,10 +765,10 @@ int build_fragments(t3mi_model* m) {
     }
     if (const char* e = std::getenv("T3MI_NORM_SPLIT")) m->norm_split = e[0] != '0';
     if (const char* e = std::getenv("T3MI_PF")) {   // attention blocks[,max (item, head) blocks[,mask[,xcd-aware[,GEMM blocks]]]]
-        int b = 0, mx = 128, mk = 15, xc = 1, gb = 0;
-        if (sscanf(e, "%d,%d,%d,%d,%d", &b, &mx, &mk, &xc, &gb) >= 1) {
+        int b = 0, mx = 128, mk = 31, xc = 1, gb = 128, mr = 16;
+        if (sscanf(e, "%d,%d,%d,%d,%d,%d", &b, &mx, &mk, &xc, &gb, &mr) >= 1) {
             auto clampb = [](int v) { return v < 0 ? 0 : (v > 1024 ? 1024 : v & ~7); };
-            m->pf_blocks = clampb(b); m->pf_gblocks = clampb(gb); m->pf_max_blocks = mx; m->pf_mask = mk; m->pf_xcd = xc;
+            m->pf_blocks = clampb(b); m->pf_gblocks = clampb(gb); m->pf_max_blocks = mx; m->pf_mask = mk; m->pf_xcd = xc; m->pf_max_rows = mr;
         }
     }
     if (m->wdtype != T3MI_W_BF16) m->pf_blocks = 0;   // the prefetch rides on the bf16 instantiations only
@@ -955,22 +955,30 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
     // Weight prefetch (t3k::PfArgs) while the (item, head) blocks of the attention launch leave CUs idle: that launch fetches o_proj's and
     // gate_up's matrices, o_proj's launch down_proj's, gate_up's launch the next layer's qkv -- each one or two launches ahead,
     // about an XCD's L2 in flight at a time.
-    const bool pf_on = m->pf_blocks > 0 && (long long)c.M * H <= m->pf_max_blocks && ((c.M * H) & 7) == 0;
-    // (experiment) more (item, head) blocks than that, one row chunk: no idle CUs in the attention launch; the qkv launch fetches instead
-    const bool pf_q = !pf_on && m->pf_blocks > 0 && (m->pf_mask & 16) && c.M <= 16 && (long long)c.M * H <= 2 * m->pf_max_blocks;
-    const size_t pf_eb = m->wdtype == T3MI_W_BF16 ? 2 : 4;
-    auto pf_region = [&](t3k::PfArgs& f, int slot, int bit, const void* w_plain, const void* w_frag, size_t elems, int K, bool remap) {
-        (void)w_plain;
+    // pf_attn: the attention launch has idle CUs (at most pf_max_blocks (item, head) blocks) and fetches o_proj's and gate_up's
+    // matrices; otherwise, up to pf_max_rows rows, the qkv launch does.
+    const bool pf_any = m->pf_blocks > 0 && as_ok && c.M <= m->pf_max_rows && ((c.M * H) & 7) == 0;
+    const bool pf_attn = pf_any && (long long)c.M * H <= m->pf_max_blocks && !(m->pf_mask & 32);
+    const bool pf_q = pf_any && !pf_attn && (m->pf_mask & 16);
+    const size_t pf_eb = 2;   // bf16 (as the instantiations that carry it)
+    auto pf_region = [&](t3k::PfArgs& f, int slot, int bit, const void* w_frag, int N, int K, int epi, bool splittable, bool remap) {
         if (!(m->pf_mask & bit) || !w_frag) return;   // only what an activation-stationary launch will read (its fragment-major image)
+        int gz = 1;
+        const int nsub = t3k::gemm_as_plan(c.M, N, K, epi, splittable, &gz);
+        if (nsub == 0) return;
         f.ptr[slot] = w_frag;
-        f.bytes[slot] = (unsigned)(elems * pf_eb);
-        // the fragment-major image is laid out by 16-feature sub-tile; at these row counts a block column of the activation-stationary
-        // kernel owns 2 of them over all of K (launch_gemm_as: NSUB = 2 below 192 blocks of 4)
-        const size_t unit = (size_t)2 * 16 * K * pf_eb;
-        if (m->pf_xcd && w_frag && (elems * pf_eb) % (8 * unit) == 0) {
+        f.bytes[slot] = (unsigned)((size_t)N * K * pf_eb);
+        // the fragment-major image is laid out by 16-feature sub-tile over all of K: a block column of the consumer owns nsub of them
+        const size_t unit = (size_t)nsub * 16 * K * pf_eb;
+        if (m->pf_xcd && f.bytes[slot] % (8 * unit) == 0) {
             f.unit[slot] = (unsigned)unit;
             f.remap[slot] = remap ? 1 : 0;
         }
+    };
+    auto pf_arm = [&](t3k::PfArgs& f, int blocks) {
+        if (f.ptr[0] == nullptr && f.ptr[1] == nullptr) return;
+        f.n_blocks = blocks;
+        f.sink = m->pf_sink.as<unsigned>();
     };
     for (int l = 0; l < m->n_layers; ++l) {
         const LayerW& lw = m->layers[l];
@@ -1008,10 +1016,9 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
             a.q = c.q; a.kcache = kc; a.vcache = vc; a.kv_bf16 = s->kv_bf16 ? 1 : 0; a.n_heads = H; a.max_len = s->max_len;
             if (turbo) { a.bias = lw.b_qkv; a.rope = 0; }
             if (pf_q && a.Wf) {
-                pf_region(a.pf, 0, 1, lw.wo, wo_f, (size_t)d * d, d, split_ln2);
-                pf_region(a.pf, 1, 2, lw.wgu, gu_f, (size_t)(turbo ? F : 2 * F) * d, d, false);
-                a.pf.n_blocks = m->pf_gblocks;
-                a.pf.sink = m->pf_sink.as<unsigned>();
+                pf_region(a.pf, 0, 1, wo_f, d, d, t3k::EPI_RESID, true, split_ln2);
+                pf_region(a.pf, 1, 2, gu_f, turbo ? F : 2 * F, d, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, false, false);
+                pf_arm(a.pf, m->pf_gblocks);
             }
             HIPCHK(t3k::launch_gemm(a, t3k::EPI_ROPE_KV, wdt, st));
         }
@@ -1022,11 +1029,10 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
             a.out = c.attn_out; a.M = c.M; a.n_heads = H; a.max_len = s->max_len;
             a.kv_bf16 = s->kv_bf16 ? 1 : 0; a.out_bf16 = abf;
             if (split_ln2 && turbo) { a.dot_vec = lw.o_colmean; a.dot_out = c.row_mu + t3k::kAsMaxRows; }
-            if (pf_on) {   // the idle CUs fetch o_proj's and gate_up's weights
-                pf_region(a.pf, 0, 1, lw.wo, wo_f, (size_t)d * d, d, split_ln2);
-                pf_region(a.pf, 1, 2, lw.wgu, gu_f, (size_t)(turbo ? F : 2 * F) * d, d, false);
-                a.pf.n_blocks = m->pf_blocks;
-                a.pf.sink = m->pf_sink.as<unsigned>();
+            if (pf_attn) {   // the idle CUs fetch o_proj's and gate_up's weights
+                pf_region(a.pf, 0, 1, wo_f, d, d, t3k::EPI_RESID, true, split_ln2);
+                pf_region(a.pf, 1, 2, gu_f, turbo ? F : 2 * F, d, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, false, false);
+                pf_arm(a.pf, m->pf_blocks);
             }
             HIPCHK(t3k::launch_attn_rows(a, st));
         }
@@ -1038,10 +1044,9 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
             if (split_ln2) { a.next_act = c.xn; a.next_norm_w = lw.ln2; a.next_ss = c.row_ss; }
             if (split_ln2 && turbo) { a.resid_mean = c.row_mu; a.row_dot = c.row_mu + t3k::kAsMaxRows; a.row_dot_n = H; a.mean_shift = lw.o_bias_mean; }
-            if ((pf_on || pf_q) && m->pf_gblocks > 0 && wo_f) {
-                pf_region(a.pf, 0, 4, lw.wdown, as_ok ? m->frag(lw.wdown, 8, c.M) : nullptr, (size_t)d * F, F, false);
-                a.pf.n_blocks = m->pf_gblocks;
-                a.pf.sink = m->pf_sink.as<unsigned>();
+            if (pf_any && m->pf_gblocks > 0 && wo_f) {
+                pf_region(a.pf, 0, 4, m->frag(lw.wdown, 8, c.M), d, F, t3k::EPI_RESID, true, false);
+                pf_arm(a.pf, m->pf_gblocks);
             }
             int ks = 1;
             a.ks_out = &ks;
@@ -1060,11 +1065,9 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
             a.W = lw.wgu; a.Wf = gu_f; a.A = c.xn; a.M = c.M; a.N = turbo ? F : 2 * F; a.K = d; a.yact = c.hact;
             a.bias = split_ln2 ? lw.b_fc_f : lw.b_fc;   // Turbo: with the split, b_ln arrives as W . b_ln in the bias (Llama: both null)
             if (split_ln2) { a.row_ss = c.row_ss; a.row_ss_tiles = d / 32; a.norm_eps = m->eps; }
-            if ((pf_on || pf_q) && m->pf_gblocks > 0 && gu_f && l + 1 < m->n_layers) {
-                const LayerW& nx = m->layers[l + 1];
-                pf_region(a.pf, 0, 8, nx.wqkv, as_ok ? m->frag(nx.wqkv, 1, c.M) : nullptr, (size_t)3 * d * d, d, false);
-                a.pf.n_blocks = m->pf_gblocks;
-                a.pf.sink = m->pf_sink.as<unsigned>();
+            if (pf_any && m->pf_gblocks > 0 && gu_f && l + 1 < m->n_layers) {
+                pf_region(a.pf, 0, 8, m->frag(m->layers[l + 1].wqkv, 1, c.M), 3 * d, d, t3k::EPI_ROPE_KV, false, false);
+                pf_arm(a.pf, m->pf_gblocks);
             }
             HIPCHK(t3k::launch_gemm(a, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, wdt, st));
         }

@@ -1,4 +1,4 @@
-# A/B of the weight prefetch from idle CUs (t3k::PfArgs), same box, alternating: T3MI_PF=0 against the default, 400-step sessions.
+# A/B of the weight prefetch from idle CUs (t3k::PfArgs), same box, alternating: T3MI_PF=0 against the default, whole sessions.
 # usage (GPU box): bash scripts/pf_ab.sh > gpurun_out/pf_ab.txt
 set -e
 run() { # variant utt s0 steps
@@ -11,10 +11,12 @@ run() { # variant utt s0 steps
   done
 }
 run turbo 8 407 300
-run turbo 4 407 300
-run turbo 2 407 300
+run turbo 12 407 300
 run turbo 16 407 300
+run turbo 32 407 300
+run llama 3 64 400
 run llama 4 64 400
-run llama 2 64 400
+run llama 6 64 400
 run llama 8 64 400
+run llama 16 64 400
 run llama 64 64 400
