@@ -183,10 +183,12 @@ struct t3mi_model {
         if (M < lo || M > hi) return nullptr;
         return static_cast<const char*>(wfrag.p) + (static_cast<const char*>(w) - static_cast<const char*>(wbuf.p));
     }
-    // weight prefetch from the attention launch's idle CUs (AttnRowsArgs::pf_ptr): blocks, the (item, head) block count up to which
-    // it runs, and which of {o_proj, gate_up, down, next qkv} are fetched
-    // Defaults from the sweep in profiles/r03_weight_prefetch_ab.txt (Turbo, 8 sentences: 0.768 -> 0.732 ms per step; Llama, 4 utterances:
-    // 0.878 -> 0.827); T3MI_PF=0 turns it off.  Runs when the attention launch has at most pf_max_blocks (item, head) blocks.
+    // Weight prefetch from idle CUs (t3k::PfArgs): up to pf_max_rows activation rows, a launch that leaves CUs
+    // idle carries extra blocks that touch the fragment-major weights the NEXT launches read, dealt so that a line lands in the L2 of
+    // the XCD whose block will read it.  pf_blocks: prefetch blocks on the attention launch (it fetches o_proj + gate_up when it has at
+    // most pf_max_blocks (item, head) blocks; with more, the qkv launch does); pf_gblocks: on a GEMM launch (o_proj fetches down,
+    // gate_up the next layer's qkv); pf_mask: 1 o_proj, 2 gate_up, 4 down, 8 next qkv, 16 the qkv launch may prefetch, 32 always the
+    // qkv launch instead of attention.  T3MI_PF=0 turns it off; A/B in profiles/r03_weight_prefetch_ab.txt.
     int pf_blocks = 128, pf_gblocks = 128, pf_max_blocks = 128, pf_mask = 31, pf_xcd = 1, pf_max_rows = 16;   // blocks on the attention launch / on a GEMM launch
     DevBuf pf_sink;   // [max(pf_blocks, pf_gblocks) * 512] words the prefetch threads leave their xor in
     int rope_len = 0;
@@ -764,7 +766,7 @@ int build_fragments(t3mi_model* m) {
         m->as_forced = true;
     }
     if (const char* e = std::getenv("T3MI_NORM_SPLIT")) m->norm_split = e[0] != '0';
-    if (const char* e = std::getenv("T3MI_PF")) {   // attention blocks[,max (item, head) blocks[,mask[,xcd-aware[,GEMM blocks]]]]
+    if (const char* e = std::getenv("T3MI_PF")) {   // attention blocks[,max (item, head) blocks[,mask[,xcd-aware[,GEMM blocks[,max rows]]]]]
         int b = 0, mx = 128, mk = 31, xc = 1, gb = 128, mr = 16;
         if (sscanf(e, "%d,%d,%d,%d,%d,%d", &b, &mx, &mk, &xc, &gb, &mr) >= 1) {
             auto clampb = [](int v) { return v < 0 ? 0 : (v > 1024 ? 1024 : v & ~7); };
