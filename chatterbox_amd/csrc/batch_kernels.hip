@@ -483,7 +483,13 @@ __global__ __launch_bounds__(64 * NW, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_k
             return;
         }
     }
-    const int h = (int)(blockIdx.x % (unsigned)a.n_heads), qi = (int)(blockIdx.x / (unsigned)a.n_heads);
+#ifdef T3K_DIAG_ATTN_SPLIT   // measurement aid (make diag; results wrong): S blocks per (item, head), each over 1/S of the keys, all writing the same row
+    const unsigned dsplit = a.diag_split > 1 ? (unsigned)a.diag_split : 1u;
+    const unsigned bx = blockIdx.x / dsplit, dsp = blockIdx.x % dsplit;
+#else
+    const unsigned bx = blockIdx.x;
+#endif
+    const int h = (int)(bx % (unsigned)a.n_heads), qi = (int)(bx / (unsigned)a.n_heads);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kg = lane >> 3, dc = lane & 7;
     const int pos = a.posmap[qi];
@@ -494,9 +500,21 @@ __global__ __launch_bounds__(64 * NW, sizeof(KVT) == 2 ? 4 : 2) void attn_rows_k
         if (a.dot_out != nullptr && tid == 0) a.dot_out[(size_t)qi * a.n_heads + h] = 0.f;
         return;
     }
-    const int L = pos + 1;
     const int crow = a.rowmap ? a.rowmap[qi] : qi;
+#ifdef T3K_DIAG_ATTN_SPLIT
+    int L = pos + 1;
+    size_t base = ((size_t)crow * a.n_heads + h) * a.max_len * kHeadDim;
+    {
+        const int Lq = (L + (int)dsplit - 1) / (int)dsplit;
+        int k0 = (int)dsp * Lq, Ls = L - k0 < Lq ? L - k0 : Lq;
+        if (Ls <= 0) { k0 = 0; Ls = 1; }
+        base += (size_t)k0 * kHeadDim;
+        L = Ls;
+    }
+#else
+    const int L = pos + 1;
     const size_t base = ((size_t)crow * a.n_heads + h) * a.max_len * kHeadDim;
+#endif
     const KVT* kp = static_cast<const KVT*>(a.kcache) + base + dc * 8;
     const KVT* vp = static_cast<const KVT*>(a.vcache) + base + dc * 8;
     float qv[8];
@@ -1874,6 +1892,17 @@ hipError_t launch_attn_rows(const AttnRowsArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
     const dim3 block(256);
+#ifdef T3K_DIAG_ATTN_SPLIT
+    {
+        static const int ds = [] { const char* e = std::getenv("T3MI_DIAG_ATTN_SPLIT"); return e ? std::atoi(e) : 0; }();
+        if (ds > 1 && a.kv_bf16 && a.out_bf16) {
+            AttnRowsArgs b = a;
+            b.diag_split = ds;
+            hipLaunchKernelGGL((attn_rows_kernel<uint16_t, uint16_t, 4>), dim3(grid.x * ds), block, 0, s, b);
+            return hipGetLastError();
+        }
+    }
+#endif
     if (a.pf.n_blocks > 0 && a.pf.sink != nullptr && (grid.x & 7) == 0 && a.kv_bf16 && a.out_bf16) {
         // few (item, head) blocks (this branch: fewer than 256): further grid rows prefetch the next launches' weights (PfArgs)
         AttnRowsArgs b = a;

@@ -234,6 +234,9 @@ struct AttnRowsArgs {
     const float* dot_vec = nullptr; // [H*64] and dot_out [M][H], both or neither: dot_out[m][h] = the stored values of head h . dot_vec's
     float* dot_out = nullptr;       // slice of head h (GemmArgs::row_dot of the o_proj launch that follows)
     PfArgs pf;                      // weight prefetch from the launch's idle CUs (few (item, head) blocks)
+#ifdef T3K_DIAG_ATTN_SPLIT
+    int diag_split = 0;             // make diag only: blocks per (item, head), each over a share of the keys (results wrong)
+#endif
 };
 hipError_t launch_attn_rows(const AttnRowsArgs& a, hipStream_t s);
 hipError_t launch_gather_rows(const float* const* src_rows, float* x, int M, int d, hipStream_t s);
