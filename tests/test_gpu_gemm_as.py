@@ -244,3 +244,44 @@ def test_activation_stationary_gemm_is_deterministic():
             assert np.array_equal(x, y)
     finally:
         m.close()
+
+
+def _open_pf(path, turbo, dims, pf):
+    old = os.environ.get("T3MI_PF")
+    if pf is None:
+        os.environ.pop("T3MI_PF", None)
+    else:
+        os.environ["T3MI_PF"] = pf      # read once, when the model is opened
+    try:
+        return (cb.load_t3_turbo if turbo else cb.load_t3)(path, device=0, dtype="bf16", start_speech_token=dims.start_speech_token,
+                                                           stop_speech_token=dims.stop_speech_token)
+    finally:
+        if old is None:
+            os.environ.pop("T3MI_PF", None)
+        else:
+            os.environ["T3MI_PF"] = old
+
+
+@pytest.mark.parametrize("name,turbo,dims,utts", [("llama-full", False, synth.FULL, [3, 4, 6, 8, 12]),
+                                                   ("turbo-full", True, synth.TURBO_FULL, [5, 8, 12, 16, 24])],
+                         ids=["llama-full", "turbo-full"])
+def test_weight_prefetch_changes_no_bit(name, turbo, dims, utts):
+    """The weight prefetch from idle CUs (t3k::PfArgs; extra grid rows of the attention / qkv / o_proj / gate_up launches at up to
+    16 activation rows) only loads: logits and tokens are bit-identical with it off (T3MI_PF=0), at its defaults, with the most
+    blocks it accepts on every launch and the qkv launch forced to carry it (mask bit 32), and with the XCD mapping off.  Row
+    counts on both sides of the 16-row limit and of the 128 / 256 (item, head) block thresholds."""
+    path = synth.ensure_turbo_checkpoint(dims, 4321) if turbo else synth.ensure_checkpoint(dims, 1234)
+    rpu = 1 if turbo else 2
+    models = [_open_pf(path, turbo, dims, pf) for pf in ("0", None, "1024,256,63,1,1024,16", "64,128,15,0,64,16")]
+    try:
+        for U in utts:
+            embs = [synth.synth_embeds(rpu, 9 + (u % 5), dims.hidden_size, 300 + u) for u in range(U)]
+            ref, toks = _run(models[0], embs, 4)
+            for m in models[1:]:
+                got, t2 = _run(m, embs, 4)
+                assert np.array_equal(t2, toks), (name, U)
+                for i in range(5):
+                    assert np.array_equal(got[i], ref[i]), (name, U, i)
+    finally:
+        for m in models:
+            m.close()
