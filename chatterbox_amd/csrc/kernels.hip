@@ -983,8 +983,37 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
         __syncthreads();
         if (sel > 0) n = compact(__uint_as_float((unsigned)sel << 23));   // tau = 2^(sel - 127)
     }
-    const int npad = next_pow2(n < 2 ? 2 : n);
-    for (int i = n + tid; i < npad; i += kSampThreads) {
+    // A support just above a power of two (the full vocabulary: 8194 entries, 8193 with the stop token masked) would sort 16384
+    // slots: instead its n - 2^k last entries of the sorted order (smallest probability, largest id among equals) are selected
+    // one by one and swapped to the tail, and the sort runs over the first 2^k.
+    int nsort = n;
+    {
+        const int p2 = next_pow2(n < 2 ? 2 : n) >> 1;
+        if (n > 1024 && n - p2 <= 4) {
+            unsigned long long* red = reinterpret_cast<unsigned long long*>(tot);
+            for (; nsort > p2; --nsort) {
+                unsigned long long best = ~0ull;   // (key, 0xFFFF - id, slot): the minimum is the last entry of the descending order
+                for (int i = tid; i < nsort; i += kSampThreads) {
+                    const unsigned long long w = ((((unsigned long long)kp[i] << 16) | (unsigned long long)(0xFFFFu - ki[i])) << 14) | (unsigned long long)i;
+                    best = w < best ? w : best;
+                }
+                red[tid] = best;
+                __syncthreads();
+                for (int o = kSampThreads >> 1; o > 0; o >>= 1) {
+                    if (tid < o && red[tid + o] < red[tid]) red[tid] = red[tid + o];
+                    __syncthreads();
+                }
+                if (tid == 0) {
+                    const int pos = (int)(red[0] & 0x3FFFull), last = nsort - 1;
+                    const uint32_t tp = kp[pos]; kp[pos] = kp[last]; kp[last] = tp;
+                    const uint16_t ti = ki[pos]; ki[pos] = ki[last]; ki[last] = ti;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    const int npad = next_pow2(nsort < 2 ? 2 : nsort);   // (== nsort when entries were moved to the tail: nothing to pad)
+    for (int i = nsort + tid; i < npad; i += kSampThreads) {
         kp[i] = 0u;
         ki[i] = 0xFFFFu;
     }
@@ -992,17 +1021,16 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
     // 5. bitonic sort: descending probability, ties by ascending id (= stable descending sort)
     for (int k = 2; k <= npad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npad; i += kSampThreads) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint32_t pa = kp[i], pb = kp[ixj];
-                    const uint16_t ia = ki[i], ib = ki[ixj];
-                    const bool a_first = (pa > pb) || (pa == pb && ia < ib);
-                    const bool up = ((i & k) == 0);
-                    if (up ? !a_first : a_first) {
-                        kp[i] = pb; kp[ixj] = pa;
-                        ki[i] = ib; ki[ixj] = ia;
-                    }
+            // one compare-exchange per thread and trip: pair q of this stage = (i, i | j) with bit j of i clear
+            for (int q = tid; q < (npad >> 1); q += kSampThreads) {
+                const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), ixj = i | j;
+                const uint32_t pa = kp[i], pb = kp[ixj];
+                const uint16_t ia = ki[i], ib = ki[ixj];
+                const bool a_first = (pa > pb) || (pa == pb && ia < ib);
+                const bool up = ((i & k) == 0);
+                if (up ? !a_first : a_first) {
+                    kp[i] = pb; kp[ixj] = pa;
+                    ki[i] = ib; ki[ixj] = ia;
                 }
             }
             __syncthreads();
@@ -1022,7 +1050,7 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
         __syncthreads();
     }
     // 6. inclusive cumsum in double, rounded to float per prefix (libtorch CPU cumsum semantics)
-    const int CH = (npad + kSampThreads - 1) / kSampThreads;
+    const int CH = ((npad > n ? npad : n) + kSampThreads - 1) / kSampThreads;
     const int i0 = tid * CH;
     double csum = 0.0;
     for (int i = i0; i < i0 + CH && i < n; ++i) csum += (double)__uint_as_float(kp[i]);

@@ -164,3 +164,24 @@ def test_hooks_reject_misuse(model):
         assert e.value.code == _lib.ERR_STATE
         with pytest.raises(ValueError):
             s.set_logits(np.zeros((1, 8194), F32))
+
+
+@pytest.mark.parametrize("masked", [0, 1, 2, 7])
+def test_full_support_order_on_device(model, dbg, masked):
+    """min_p = 0 and a top_p no cumulative sum exceeds: nothing is filtered and the kernel sorts the whole vocabulary (R/t3.R:551,
+    descending probability; equal probabilities in ascending id order, as the oracle's stable sort).  8194 and 8193 entries sit
+    just above 8192, where the kernel moves the last entries of the order to the tail by selection and sorts 8192 slots; 8192
+    and 8187 take the plain sort.  The reference's logits quantised to steps of 0.5, so that hundreds of entries tie."""
+    raw = np.ascontiguousarray(np.round(dbg["raw_logits_step0"] * 2) / 2, dtype=F32)
+    gone = [17, 4096, 8193, 8192, 1, 5000, 6561][:masked]
+    raw[:, gone] = F32(-1e4)      # probability underflows to 0: not part of the support
+    kw = dict(cfg_weight=0.5, temperature=0.8, repetition_penalty=1.0, min_p=0.0, top_p=2.0)
+    _, ids, pr, drawn, _ = _step(model, raw, seed=11, **kw)
+    t = O.sampling_tail(O.cfg_combine(raw, 0.5), [], O.SampleParams(**{k: v for k, v in kw.items() if k != "cfg_weight"}),
+                        O.counter_uniform(11, 0, 0))
+    n = int((np.asarray(t.sorted_probs) > 0).sum())
+    assert n == 8194 - masked == len(ids)
+    assert list(ids) == [int(i) for i in t.sorted_idx[:n]]
+    assert len(set(int(i) for i in ids[-8:]) & set(gone)) == 0
+    np.testing.assert_allclose(pr, np.asarray(t.sorted_probs[:n], dtype=np.float64), rtol=2e-3, atol=1e-12)
+    assert drawn in [int(i) for i in ids]
