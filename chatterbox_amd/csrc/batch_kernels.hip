@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     constexpr int NT = MC / 16;              // accumulator tiles per wave = staging pieces per thread and phase
     constexpr int LDA = KB + E;              // LDS row stride in elements (+16 B: 16-row fragment reads fall in distinct banks)
     constexpr int RS = kAsRedStride;
-    static_assert(NPH >= 2 && NPH <= 8, "2 to 8 staging phases");
+    static_assert(NPH >= 2 && NPH <= 16, "2 to 16 staging phases");
     constexpr int kLdsMain = (MC * LDA * (int)sizeof(T)) > (8 * MC * RS * 4) ? (MC * LDA * (int)sizeof(T)) : (8 * MC * RS * 4);
     extern __shared__ __attribute__((aligned(16))) unsigned char as_raw[];
     T* lds = reinterpret_cast<T*>(as_raw);   // [MC][LDA], later float red[KW][NSUB][MC][RS]
@@ -1282,6 +1282,16 @@ __global__ __launch_bounds__(512) void gemm_as_kernel(GemmArgs a, int tiles32) {
     phase(std::integral_constant<int, 5>{});
     phase(std::integral_constant<int, 6>{});
     phase(std::integral_constant<int, 7>{});
+    if constexpr (NPH > 8) {   // K = 4096 unsplit (down_proj as the producer of the next layer's split norm)
+        phase(std::integral_constant<int, 8>{});
+        phase(std::integral_constant<int, 9>{});
+        phase(std::integral_constant<int, 10>{});
+        phase(std::integral_constant<int, 11>{});
+        phase(std::integral_constant<int, 12>{});
+        phase(std::integral_constant<int, 13>{});
+        phase(std::integral_constant<int, 14>{});
+        phase(std::integral_constant<int, 15>{});
+    }
     T3K_DBG_STAMP(2);
     if constexpr (NRM == 1) {   // 16 lanes per row add their partial sums in a fixed butterfly order
         float sv = ssa + ssb;
@@ -1547,7 +1557,7 @@ inline bool as_four(int tiles32, int chunks, int gz) { return (long long)((2 * t
 
 template <int EPI, typename T, int NSUB, int KB>
 hipError_t launch_gemm_as_m(const GemmArgs& a, int tiles32, int gz, hipStream_t s) {
-    if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GELU) {
+    if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GELU || EPI == EPI_ROPE_KV) {
         if (a.row_ss != nullptr) {
             if (as_chunk_rows<T>(a.M) == 16) return launch_gemm_as_v<EPI, T, NSUB, KB, 16, 1>(a, tiles32, gz, s);
             return launch_gemm_as_v<EPI, T, NSUB, KB, 32, 1>(a, tiles32, gz, s);
@@ -1573,6 +1583,15 @@ hipError_t launch_gemm_as(const GemmArgs& a, hipStream_t s, bool& handled) {
     handled = false;
     const bool splittable = (EPI == EPI_RESID || EPI == EPI_STORE) && a.part != nullptr;
     if (EPI == EPI_SWIGLU && a.N % 32) return hipSuccess;
+    if constexpr (EPI == EPI_RESID && sizeof(T) == 2) {
+        // down_proj as the producer of the NEXT layer's pre-attention RMS norm: K = 4096 unsplit in 16-row chunks (128 KB of LDS), so
+        // that the rows leave the block complete -- no partial slabs and no norm launch to fold them (the caller passes no `part`)
+        if (a.next_act != nullptr && a.row_dot == nullptr && a.part == nullptr && a.K == 4096 && (a.N % 32) == 0 && a.next_norm_w && a.next_ss) {
+            handled = true;
+            if (a.ks_out != nullptr) *a.ks_out = 1;
+            return launch_gemm_as_v<EPI_RESID, T, 2, 4096, 16, 2>(a, tiles32_of<EPI>(a.N), 1, s);
+        }
+    }
     const int mc = as_chunk_rows<T>(a.M);
     const int tiles32 = tiles32_of<EPI>(a.N), chunks = (a.M + mc - 1) / mc;
     // the block's K range: all of K (1024 or 512), or for the residual GEMMs a split into fp32 partial slabs -- 1024 k
@@ -1589,7 +1608,7 @@ hipError_t launch_gemm_as(const GemmArgs& a, hipStream_t s, bool& handled) {
     if (a.next_act != nullptr && (EPI != EPI_RESID || gz != 1 || (a.N % 32) || !a.next_norm_w || !a.next_ss)) return hipSuccess;
     if ((a.row_dot != nullptr) != (a.resid_mean != nullptr) || (a.row_dot != nullptr && (a.next_act == nullptr || a.row_dot_n < 1 || a.row_dot_n > 32)))
         return hipSuccess;
-    if (a.row_ss != nullptr && ((EPI != EPI_SWIGLU && EPI != EPI_GELU) || a.row_ss_tiles < 1 || a.row_ss_tiles > 32)) return hipSuccess;
+    if (a.row_ss != nullptr && ((EPI != EPI_SWIGLU && EPI != EPI_GELU && EPI != EPI_ROPE_KV) || a.row_ss_tiles < 1 || a.row_ss_tiles > 32)) return hipSuccess;
     const bool four = as_four(tiles32, chunks, gz);
     handled = true;
     hipError_t e;

@@ -151,7 +151,10 @@ struct t3mi_model {
     DevBuf wbuf, small, emb, pos_emb, rope_cos, rope_sin;
     DevBuf wfrag;                      // bf16 models: the streamed matrices once more, fragment-major, at wbuf's offsets (build_fragments)
     int as_mask = 15;                  // which GEMMs may take it: 1 qkv, 2 o_proj, 4 gate_up / c_fc, 8 down, 16 head
-    bool norm_split = true;            // T3MI_NORM_SPLIT=0: Llama's post-attention norm stays a launch of its own
+    int norm_split = 1;                // T3MI_NORM_SPLIT: bit 1 the post-attention norm is split over o_proj / gate_up; bit 2 (experiment, measured
+                                       // slower: profiles/r03_ln1_split_ab.txt) Llama's pre-attention norm over down_proj / the next layer's qkv;
+                                       // 0: every norm is a launch of its own
+    int ln1_lo = 17, ln1_hi = 128;     // row range of the pre-attention split (T3MI_LN1_ROWS=lo,hi)
     bool as_forced = false;            // T3MI_AS=<mask> set: exactly the named GEMMs take it at every row count the kernel accepts (tests, A/B runs)
     // The fragment-major twin of a matrix in wbuf for a launch of M rows, or nullptr (the LDS-staged kernels then run).
     // Row ranges per GEMM, measured over 400-step sessions (profiles/r02_gemm_as_ab.txt).  bf16: qkv wins up to 1024
@@ -765,7 +768,8 @@ int build_fragments(t3mi_model* m) {
         m->as_mask = std::atoi(e) & 31;
         m->as_forced = true;
     }
-    if (const char* e = std::getenv("T3MI_NORM_SPLIT")) m->norm_split = e[0] != '0';
+    if (const char* e = std::getenv("T3MI_NORM_SPLIT")) m->norm_split = std::atoi(e);   // bit 1: post-attention norm, bit 2: pre-attention (Llama)
+    if (const char* e = std::getenv("T3MI_LN1_ROWS")) sscanf(e, "%d,%d", &m->ln1_lo, &m->ln1_hi);
     if (const char* e = std::getenv("T3MI_PF")) {   // attention blocks[,max (item, head) blocks[,mask[,xcd-aware[,GEMM blocks[,max rows]]]]]
         int b = 0, mx = 128, mk = 31, xc = 1, gb = 128, mr = 16;
         if (sscanf(e, "%d,%d,%d,%d,%d,%d", &b, &mx, &mk, &xc, &gb, &mr) >= 1) {
@@ -982,6 +986,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
         f.n_blocks = blocks;
         f.sink = m->pf_sink.as<unsigned>();
     };
+    bool ln1_done = false;
     for (int l = 0; l < m->n_layers; ++l) {
         const LayerW& lw = m->layers[l];
         char* kc = s->kc.as<char>() + layer_kv * l;
@@ -998,17 +1003,18 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
         bool split_ln2 = false;
         // (measured, Llama bf16, ms per step without -> with: 4 utterances 0.929 -> 0.875, 16: 1.056 -> 1.009, 32: 1.303 -> 1.293, 64: 1.804 ->
         // 1.773, 96: 2.349 -> 2.340, 128: 2.764 -> 2.762, 192: 3.741 -> 3.753: up to 128 rows)
-        if (m->norm_split && c.row_ss != nullptr && gu_f != nullptr && d % 32 == 0 && d / 32 <= 32 && c.M <= 128 && t3k::gemm_as_takes(c.M, d) &&
+        if ((m->norm_split & 1) && c.row_ss != nullptr && gu_f != nullptr && d % 32 == 0 && d / 32 <= 32 && c.M <= 128 && t3k::gemm_as_takes(c.M, d) &&
             (!turbo || (c.row_mu != nullptr && lw.o_colmean != nullptr && H <= 32 && (abf || c.M <= 32)))) {
             // (Turbo, S0 407, ms per step without -> with; bf16: 8 sentences 0.826 -> 0.787, 16: 0.870 -> 0.830, 32: 0.995 -> 0.953, 64: 1.321 ->
             // 1.300, 128: 1.991 -> 1.957; fp32: 8: 1.216 -> 1.216, 16: 1.272 -> 1.254, 32: 1.573 -> 1.557, 64: 2.345 -> 2.414: fp32 up to 32 rows)
             const void* any = m->frag(lw.wo, 2, c.M, true);   // o_proj below its tuned row range still pays for itself here
             if (any != nullptr) { wo_f = any; split_ln2 = true; }
         }
+        // ln1_done: the previous layer's down_proj left w_ln1 * x in xn and the per-tile sums of squares in row_ss (below)
         if (turbo)
             HIPCHK(t3k::launch_layernorm_rows(c.x, lw.ln1, lw.ln1_b, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias,
                                               split_ln2 ? c.row_mu : nullptr));
-        else HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln1, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias));
+        else if (!ln1_done) HIPCHK(t3k::launch_rmsnorm_rows(c.x, lw.ln1, m->eps, c.xn, c.M, d, abf, st, gp, c.pend_ks, c.pend_bias));
         c.pend_ks = 0;
         {
             t3k::GemmArgs a;
@@ -1017,6 +1023,7 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
             a.rope_cos = m->rope_cos.as<float>(); a.rope_sin = m->rope_sin.as<float>();
             a.q = c.q; a.kcache = kc; a.vcache = vc; a.kv_bf16 = s->kv_bf16 ? 1 : 0; a.n_heads = H; a.max_len = s->max_len;
             if (turbo) { a.bias = lw.b_qkv; a.rope = 0; }
+            if (ln1_done) { a.row_ss = c.row_ss; a.row_ss_tiles = d / 32; a.norm_eps = m->eps; }
             if (pf_q && a.Wf) {
                 pf_region(a.pf, 0, 1, wo_f, d, d, t3k::EPI_RESID, true, split_ln2);
                 pf_region(a.pf, 1, 2, gu_f, turbo ? F : 2 * F, d, turbo ? t3k::EPI_GELU : t3k::EPI_SWIGLU, false, false);
@@ -1079,6 +1086,14 @@ int run_layers_gemm(t3mi_model* m, Session* s, GemmCtx& c, StepTimer* tm) {
             a.W = lw.wdown; a.Wf = as_ok ? m->frag(lw.wdown, 8, c.M) : nullptr; a.A = c.hact; a.M = c.M; a.N = d; a.K = F;
             a.y = c.x; a.resid = c.x; a.ldy = d; a.bias = lw.b_down;
             a.part = s->gpart.as<float>(); a.part_floats = s->gpart.bytes / 4;
+            // Llama's pre-attention norm of the NEXT layer split like the post-attention one: down_proj with K unsplit (16-row chunks, all
+            // of K in LDS) writes x, w_ln1 * x in the activation type and per-tile sums of squares; the next qkv scales its rows before
+            // RoPE.  Removes the norm launch and down_proj's partial slabs -- and measured SLOWER (64 utterances 1.758 -> 1.770 ms per step,
+            // 16 utterances 1.007 -> 1.074: down_proj 6.7 -> 10.1 us, qkv 6.5 -> 7.5, against 4.9 for the norm launch), so it is off by default.
+            ln1_done = (m->norm_split & 2) && !turbo && abf && c.row_ss != nullptr && l + 1 < m->n_layers && F == 4096 && d % 32 == 0 &&
+                       d / 32 <= 32 && c.M >= m->ln1_lo && c.M <= m->ln1_hi && c.M <= 128 && a.Wf != nullptr &&
+                       m->frag(m->layers[l + 1].wqkv, 1, c.M) != nullptr;
+            if (ln1_done) { a.part = nullptr; a.part_floats = 0; a.next_act = c.xn; a.next_norm_w = m->layers[l + 1].ln1; a.next_ss = c.row_ss; }
             int ks = 1;
             a.ks_out = &ks;
             HIPCHK(t3k::launch_gemm(a, t3k::EPI_RESID, wdt, st));
