@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
     for (int i = tid; i < kkeep; i += kSampThreads) s3 += __uint_as_float(kp[i]);
     s3 = block_reduce_sum(s3, scratch);
     // 8. draw: inverse CDF over the kept prefix with the build's counter RNG
-    const float uu = counter_uniform(a.seed, a.utt_base + (unsigned long long)u, (unsigned long long)step);
+    const float uu = counter_uniform(a.seed, a.utt_ids[u], (unsigned long long)step);
     const float target = __fmul_rn(uu, kkeep > 0 ? cum[kkeep - 1] : 0.f);
     if (tid == 0) misc[2] = 0;
     __syncthreads();
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(kSampThreads) void sampler_kernel(SamplerArgs a, in
     // 9. bookkeeping + next-token embedding (R/t3.R:569-587; src/t3_decode.cpp:365-388)
     const int pos_next = a.s0[u] + step;  // cache slot of the token just sampled
     int dn = 0;
-    int max_new = a.max_new_tokens;
+    int max_new = a.max_new_u[u];   // this slot's own limit (<= the session's; t3mi_session_refill may lower it)
     if (a.cache_cap > 0) max_new = min(max_new, a.cache_cap - a.s0[u] - 1 + a.cap_extra);   // per utterance, R/t3.R:996
     if (tok == a.stop_token) dn = 1;
     else if (step + 1 >= max_new) dn = 2;

@@ -162,7 +162,8 @@ struct SamplerArgs {
     float cfg_w = 0.f, temperature = 1.f, top_p = 1.f, min_p = 0.f, penalty = 1.f;
     int variant = 0, top_k = 0, stop_token = -1, start_token = -1, mask_stop = 0, max_new_tokens = 0;
     unsigned long long seed = 0;
-    unsigned long long utt_base = 0;  // global index of utterance 0 (RNG stream = seed, utt_base + u)
+    const unsigned long long* utt_ids = nullptr;  // [n_utt] global index of the utterance in each slot (RNG stream = seed, utt_ids[u])
+    const int* max_new_u = nullptr;  // [n_utt] token limit of each slot (max_new_tokens, or what t3mi_session_refill gave the slot)
     int cache_cap = 0;            // > 0: utterance u stops after min(max_new_tokens, cache_cap - s0[u] - 1 + cap_extra) tokens
     int cap_extra = 0;            // Turbo: +1 (first token comes from the prefill logits)
     uint8_t* seen = nullptr;      // [n_utt, V]

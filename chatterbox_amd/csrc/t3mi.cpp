@@ -10,6 +10,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -127,8 +128,10 @@ struct Session {
     std::vector<int32_t> s0;
     DevBuf kc, vc, x, qbuf, pm, pl, pacc, hbuf, logits, rope_cur, rowpos, start, emb_rows, emb_data, seen, tokens, n_tokens,
         done, s0_dev, forced, dist_ids, dist_probs, dist_n, drawn;
+    DevBuf utt_ids, max_new_u;  // [n_utt] global utterance index (RNG stream) and token limit of each slot (t3mi_session_refill changes them)
     DevBuf filt;                // [n_utt][V] logits after CFG / penalty / temperature (t3mi_session_keep_filtered), else empty
     int n_forced = 0;
+    bool gemm_prefill = true, pf_act_f32 = false;   // how session_begin prefilled (t3mi_session_refill does the same)
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     bool graph_tried = false;
@@ -1165,7 +1168,7 @@ int run_sampler(t3mi_model* m, Session* s, StepTimer* tm) {
     a.cfg_w = p.cfg_weight; a.temperature = p.temperature; a.top_p = p.top_p; a.min_p = p.min_p;
     a.penalty = p.repetition_penalty; a.variant = p.sampler; a.top_k = p.top_k; a.stop_token = p.stop_token;
     a.mask_stop = p.mask_stop; a.max_new_tokens = p.max_new_tokens; a.seed = p.seed;
-    a.utt_base = (unsigned long long)p.first_utterance_id;
+    a.utt_ids = s->utt_ids.as<unsigned long long>(); a.max_new_u = s->max_new_u.as<int>();
     a.cache_cap = p.max_cache_len > 0 ? p.max_cache_len : 0;
     a.cap_extra = m->variant == T3MI_VARIANT_TURBO ? 1 : 0;
     a.start_token = p.start_token;
@@ -1214,6 +1217,78 @@ int build_graph(t3mi_model* m, Session* s) {
     if (e != hipSuccess) return fail(T3MI_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
     s->graph = g;
     HIPCHK(hipGraphInstantiate(&s->gexec, g, nullptr, nullptr, 0));
+    return T3MI_OK;
+}
+
+// ---- prefill of a list of session rows (R/t3.R:505): all prompt positions of the listed rows as ONE list of (row, position) items
+// through the MFMA GEMM path (run_layers_gemm with posmap / rowmap), the last position's hidden state of each row left in s->x.
+// rows_list: ascending session rows (row = utterance * rpu + r); row_ptr[i]: device address of the [s0, d] prompt of rows_list[i];
+// the prompt length of a row is s->s0[row / rpu].  Rows are prefilled in groups of at most kPrefillItems items (a row only attends
+// to its own cache row, so groups are independent): the scratch stays bounded however many prompts a batch holds.
+int prefill_rows(t3mi_model* m, Session* s, const std::vector<int>& rows_list, const std::vector<const float*>& row_ptr, bool pf_act_f32) {
+    constexpr size_t kPrefillItems = 32768;
+    const size_t d = m->d, F = m->F;
+    const int rpu = s->rpu;
+    hipStream_t st = m->stream;
+    const int nr = (int)rows_list.size();
+    std::vector<std::pair<int, int>> groups;   // [begin, end) into rows_list
+    size_t max_items = 0;
+    for (int i0 = 0; i0 < nr;) {
+        size_t n = 0;
+        int i1 = i0;
+        while (i1 < nr && (i1 == i0 || n + (size_t)s->s0[rows_list[i1] / rpu] <= kPrefillItems)) n += (size_t)s->s0[rows_list[i1++] / rpu];
+        groups.emplace_back(i0, i1);
+        max_items = std::max(max_items, n);
+        i0 = i1;
+    }
+    DevBuf xpf, qpf, xnpf, aopf, hpf, dsrc, dpos, drow, dlast;
+    const size_t as = (m->wdtype == T3MI_W_BF16 && !pf_act_f32) ? 2 : 4;
+    HIPCHK(xpf.alloc(max_items * d * 4));
+    HIPCHK(qpf.alloc(max_items * d * 4));
+    HIPCHK(xnpf.alloc(max_items * d * as));
+    HIPCHK(aopf.alloc(max_items * d * as));
+    HIPCHK(hpf.alloc(max_items * F * as));
+    HIPCHK(dsrc.alloc(max_items * sizeof(void*)));
+    HIPCHK(dpos.alloc(max_items * 4));
+    HIPCHK(drow.alloc(max_items * 4));
+    HIPCHK(dlast.alloc((size_t)nr * sizeof(void*)));
+    std::vector<const float*> isrc, last;
+    std::vector<int32_t> ipos, irow;
+    int rc;
+    for (const auto& grp : groups) {
+        isrc.clear(); ipos.clear(); irow.clear(); last.clear();
+        for (int i = grp.first; i < grp.second; ++i) {
+            const int r = rows_list[i], u = r / rpu;
+            for (int t = 0; t < s->s0[u]; ++t) {
+                isrc.push_back(row_ptr[i] + (size_t)t * d);
+                ipos.push_back(t);
+                irow.push_back(r);
+            }
+            last.push_back(xpf.as<float>() + (isrc.size() - 1) * d);
+        }
+        const size_t items = isrc.size();
+        const int grows = grp.second - grp.first;
+        HIPCHK(hipMemcpyAsync(dsrc.p, isrc.data(), items * sizeof(void*), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dpos.p, ipos.data(), items * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(drow.p, irow.data(), items * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dlast.p, last.data(), (size_t)grows * sizeof(void*), hipMemcpyHostToDevice, st));
+        HIPCHK(t3k::launch_gather_rows(dsrc.as<const float*>(), xpf.as<float>(), (int)items, m->d, st));
+        GemmCtx c;
+        c.M = (int)items; c.x = xpf.as<float>(); c.q = qpf.as<float>();
+        c.xn = xnpf.p; c.attn_out = aopf.p; c.hact = hpf.p;
+        c.posmap = dpos.as<int>(); c.rowmap = drow.as<int>();
+        c.act_f32 = pf_act_f32;
+        if ((rc = run_layers_gemm(m, s, c, nullptr))) return rc;
+        if ((rc = fold_pending(m, s, c))) return rc;
+        // the last prompt position of every row feeds the first speech-head evaluation: runs of consecutive session rows at a time
+        for (int i = grp.first; i < grp.second;) {
+            int j = i + 1;
+            while (j < grp.second && rows_list[j] == rows_list[j - 1] + 1) ++j;
+            HIPCHK(t3k::launch_gather_rows(dlast.as<const float*>() + (i - grp.first), s->x.as<float>() + (size_t)rows_list[i] * d, j - i, m->d, st));
+            i = j;
+        }
+        HIPCHK(hipStreamSynchronize(st));  // the host vectors are refilled by the next group; the scratch dies after the last
+    }
     return T3MI_OK;
 }
 
@@ -1482,7 +1557,16 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     HIPCHK(s->dist_probs.alloc(U * V * 4));
     HIPCHK(s->dist_n.alloc(U * 4));
     HIPCHK(s->drawn.alloc(U * 4));
+    HIPCHK(s->utt_ids.alloc(U * 8));
+    HIPCHK(s->max_new_u.alloc(U * 4));
     hipStream_t st = m->stream;
+    {
+        std::vector<unsigned long long> ids(U);
+        std::vector<int32_t> mn(U, max_new);
+        for (size_t u = 0; u < U; ++u) ids[u] = (unsigned long long)p->first_utterance_id + u;
+        HIPCHK(hipMemcpy(s->utt_ids.p, ids.data(), U * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(s->max_new_u.p, mn.data(), U * 4, hipMemcpyHostToDevice));
+    }
     // create_kv_cache zero-fills the slabs (R/llama_traced.R:276-283)
     HIPCHK(hipMemsetAsync(s->kc.p, 0, kv, st));
     HIPCHK(hipMemsetAsync(s->vc.p, 0, kv, st));
@@ -1547,62 +1631,11 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
     if (pfenv && std::strcmp(pfenv, "token") == 0) gemm_prefill = false;
     if (pfenv && std::strcmp(pfenv, "gemm") == 0) gemm_prefill = true;
     if (s->kv_bf16) gemm_prefill = true;   // the one-position decode kernels write fp32 cache slots
+    s->gemm_prefill = gemm_prefill; s->pf_act_f32 = pf_act_f32;
     if (gemm_prefill) {
-        // Rows are prefilled in groups of at most kPrefillItems (row, position) items (a row only attends to its own
-        // cache row, so groups are independent): the scratch stays bounded however many prompts a batch holds.
-        constexpr size_t kPrefillItems = 32768;
-        std::vector<std::pair<int, int>> groups;   // [row begin, row end)
-        size_t max_items = 0;
-        for (int r0 = 0; r0 < (int)rows;) {
-            size_t n = 0;
-            int r1 = r0;
-            while (r1 < (int)rows && (r1 == r0 || n + (size_t)s0[r1 / rpu] <= kPrefillItems)) n += (size_t)s0[r1++ / rpu];
-            groups.emplace_back(r0, r1);
-            max_items = std::max(max_items, n);
-            r0 = r1;
-        }
-        DevBuf xpf, qpf, xnpf, aopf, hpf, dsrc, dpos, drow, dlast;
-        const size_t as = (m->wdtype == T3MI_W_BF16 && !pf_act_f32) ? 2 : 4;
-        HIPCHK(xpf.alloc(max_items * d * 4));
-        HIPCHK(qpf.alloc(max_items * d * 4));
-        HIPCHK(xnpf.alloc(max_items * d * as));
-        HIPCHK(aopf.alloc(max_items * d * as));
-        HIPCHK(hpf.alloc(max_items * F * as));
-        HIPCHK(dsrc.alloc(max_items * sizeof(void*)));
-        HIPCHK(dpos.alloc(max_items * 4));
-        HIPCHK(drow.alloc(max_items * 4));
-        HIPCHK(dlast.alloc(rows * sizeof(void*)));
-        std::vector<const float*> isrc, last;
-        std::vector<int32_t> ipos, irow;
-        for (const auto& grp : groups) {
-            isrc.clear(); ipos.clear(); irow.clear(); last.clear();
-            for (int r = grp.first; r < grp.second; ++r) {
-                const int u = r / rpu;
-                for (int t = 0; t < s0[u]; ++t) {
-                    isrc.push_back(row_ptr[r] + (size_t)t * d);
-                    ipos.push_back(t);
-                    irow.push_back(r);
-                }
-                last.push_back(xpf.as<float>() + (isrc.size() - 1) * d);
-            }
-            const size_t items = isrc.size();
-            const int grows = grp.second - grp.first;
-            HIPCHK(hipMemcpyAsync(dsrc.p, isrc.data(), items * sizeof(void*), hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dpos.p, ipos.data(), items * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(drow.p, irow.data(), items * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(dlast.p, last.data(), (size_t)grows * sizeof(void*), hipMemcpyHostToDevice, st));
-            HIPCHK(t3k::launch_gather_rows(dsrc.as<const float*>(), xpf.as<float>(), (int)items, m->d, st));
-            GemmCtx c;
-            c.M = (int)items; c.x = xpf.as<float>(); c.q = qpf.as<float>();
-            c.xn = xnpf.p; c.attn_out = aopf.p; c.hact = hpf.p;
-            c.posmap = dpos.as<int>(); c.rowmap = drow.as<int>();
-            c.act_f32 = pf_act_f32;
-            if ((rc = run_layers_gemm(m, s.get(), c, nullptr))) return rc;
-            if ((rc = fold_pending(m, s.get(), c))) return rc;
-            // the last prompt position of every row feeds the first speech-head evaluation
-            HIPCHK(t3k::launch_gather_rows(dlast.as<const float*>(), s->x.as<float>() + (size_t)grp.first * d, grows, m->d, st));
-            HIPCHK(hipStreamSynchronize(st));  // the host vectors are refilled by the next group; the scratch dies after the last
-        }
+        std::vector<int> all_rows(rows);
+        for (size_t r = 0; r < rows; ++r) all_rows[r] = (int)r;
+        if ((rc = prefill_rows(m, s.get(), all_rows, row_ptr, pf_act_f32))) return rc;
     } else {
         for (int t = 0; t < max_s0; ++t) {
             t3k::EmbedArgs e;
@@ -2071,6 +2104,264 @@ int t3mi_session_begin_tokens(t3mi_model* m, int n_utt, const t3mi_cond* conds, 
     int rc = build_prompts(m, n_utt, conds, text_tokens, n_text, p->cfg_weight, p->start_token, ptrs, s0, &rpu);
     if (rc) return rc;
     return t3mi_session_begin(m, n_utt, rpu, ptrs.data(), s0.data(), p, 1);
+}
+
+// Continuous batching: slots of the running session whose utterance has ended (or any slot) take new utterances while the others keep
+// their state.  Their prompts are prefilled together (the same kernels as t3mi_session_begin), their cache rows are simply
+// overwritten from position 0 (attention never reads a slot beyond the row's position), the per-slot state restarts, and the first
+// logits of ALL rows are re-evaluated from the resident hidden states (bit-identical for the untouched rows).
+int t3mi_session_refill(t3mi_model* m, int n, const int32_t* utts, const float* const* embeds, const int32_t* s0,
+                        const int32_t* max_new_tokens, const int64_t* utterance_ids, int embeds_on_device) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    Session* s = m->sess.get();
+    if (n <= 0 || !utts || !embeds || !s0) return fail(T3MI_ERR_ARG, "t3mi_session_refill: empty or null argument");
+    if (!s->gemm_prefill) return fail(T3MI_ERR_STATE, "t3mi_session_refill needs the GEMM prefill (T3MI_PREFILL=token is set)");
+    if (s->n_forced > 0) return fail(T3MI_ERR_STATE, "t3mi_session_refill: the session runs teacher-forced (t3mi_session_force)");
+    const bool turbo = m->variant == T3MI_VARIANT_TURBO;
+    const int rpu = s->rpu;
+    const size_t d = m->d, V = m->V;
+    std::vector<char> taken(s->n_utt, 0);
+    std::vector<int32_t> mn(n);
+    for (int i = 0; i < n; ++i) {
+        const int u = utts[i];
+        if (u < 0 || u >= s->n_utt) return fail(T3MI_ERR_ARG, "t3mi_session_refill: slot " + std::to_string(u) + " outside the session");
+        if (taken[u]) return fail(T3MI_ERR_ARG, "t3mi_session_refill: slot " + std::to_string(u) + " listed twice");
+        taken[u] = 1;
+        if (!embeds[i] || s0[i] <= 0) return fail(T3MI_ERR_ARG, "t3mi_session_refill: null or empty prompt");
+        // the cache rows were sized by t3mi_session_begin: prompt + one token at least must fit (the sampler stops a row at the end
+        // of its slab, status 3), and under max_cache_len the rule of R/llama_traced.R:343-345 applies
+        const int limit = s->prm.max_cache_len > 0 ? s->prm.max_cache_len : s->max_len;
+        if (s0[i] + 1 >= limit)
+            return fail(T3MI_ERR_ARG, "t3mi_session_refill: prompt of " + std::to_string(s0[i]) + " positions does not fit the session's cache rows (" +
+                                          std::to_string(limit) + " slots)");
+        int want = max_new_tokens ? max_new_tokens[i] : s->prm.max_new_tokens - (turbo ? 1 : 0);
+        if (want <= 0) return fail(T3MI_ERR_ARG, "t3mi_session_refill: max_new_tokens must be positive");
+        if (turbo) want += 1;   // the first token comes from the prefill logits (R/t3.R:1614-1658)
+        mn[i] = std::min(want, s->cap);
+    }
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    HIPCHK(hipStreamSynchronize(st));   // the steps enqueued so far are over: the slots' tokens were the caller's to read before this call
+    // prompts to the device
+    DevBuf stage;
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return utts[a] < utts[b]; });
+    std::vector<const float*> base(n);
+    if (embeds_on_device) {
+        for (int i = 0; i < n; ++i) base[i] = embeds[i];
+    } else {
+        size_t tot = 0;
+        for (int i = 0; i < n; ++i) tot += (size_t)rpu * s0[i] * d;
+        HIPCHK(stage.alloc(tot * 4));
+        size_t off = 0;
+        for (int i = 0; i < n; ++i) {
+            const size_t cnt = (size_t)rpu * s0[i] * d;
+            HIPCHK(hipMemcpyAsync(stage.as<float>() + off, embeds[i], cnt * 4, hipMemcpyHostToDevice, st));
+            base[i] = stage.as<float>() + off;
+            off += cnt;
+        }
+    }
+    std::vector<int> rows_list;
+    std::vector<const float*> row_ptr;
+    for (int oi = 0; oi < n; ++oi) {
+        const int i = order[oi], u = utts[i];
+        s->s0[u] = s0[i];
+        for (int r = 0; r < rpu; ++r) {
+            rows_list.push_back(u * rpu + r);
+            row_ptr.push_back(base[i] + (size_t)r * s0[i] * d);
+        }
+    }
+    s->max_s0 = *std::max_element(s->s0.begin(), s->s0.end());
+    if ((rc = prefill_rows(m, s, rows_list, row_ptr, s->pf_act_f32))) return rc;
+    // per-slot state: token count, end flag, seen set (Q3: column BOS - 1 from the first step on), prompt length, limit, RNG stream
+    for (int i = 0; i < n; ++i) {
+        const int u = utts[i];
+        const int32_t zero = 0, s0v = s0[i];
+        const unsigned long long id = utterance_ids ? (unsigned long long)utterance_ids[i] : (unsigned long long)s->prm.first_utterance_id + (unsigned long long)u;
+        HIPCHK(hipMemsetAsync(s->seen.as<uint8_t>() + (size_t)u * V, 0, V, st));
+        if (s->prm.sampler == T3MI_SAMPLER_R && s->prm.repetition_penalty != 1.0f) {
+            const int col = s->prm.start_token - 1;
+            if (col >= 0 && col < m->V) HIPCHK(hipMemsetAsync(s->seen.as<uint8_t>() + (size_t)u * V + col, 1, 1, st));
+        }
+        HIPCHK(hipMemsetAsync(s->tokens.as<int>() + (size_t)u * s->cap, 0, (size_t)s->cap * 4, st));
+        HIPCHK(hipMemcpyAsync(s->n_tokens.as<int>() + u, &zero, 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->done.as<int>() + u, &zero, 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->dist_n.as<int>() + u, &zero, 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->s0_dev.as<int>() + u, &s0v, 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->max_new_u.as<int>() + u, &mn[i], 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->utt_ids.as<unsigned long long>() + u, &id, 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));   // (the sources are locals)
+    }
+    if ((rc = run_head(m, s, nullptr))) return rc;
+    HIPCHK(hipStreamSynchronize(st));
+    return T3MI_OK;
+}
+
+int t3mi_session_refill_tokens(t3mi_model* m, int n, const int32_t* utts, const t3mi_cond* conds, const int32_t* const* text_tokens,
+                               const int32_t* n_text, const int32_t* max_new_tokens, const int64_t* utterance_ids) {
+    int rc = need_session(m);
+    if (rc) return rc;
+    Session* s = m->sess.get();
+    std::vector<const float*> ptrs;
+    std::vector<int32_t> s0;
+    int rpu = 1;
+    rc = build_prompts(m, n, conds, text_tokens, n_text, s->prm.cfg_weight, s->prm.start_token, ptrs, s0, &rpu);
+    if (rc) return rc;
+    if (rpu != s->rpu) return fail(T3MI_ERR_ARG, "t3mi_session_refill_tokens: the prompt has another number of rows than the session's utterances");
+    return t3mi_session_refill(m, n, utts, ptrs.data(), s0.data(), max_new_tokens, utterance_ids, 1);
+}
+
+// ---- continuous batching driver: n_utt utterances through `slots` session slots (t3mi_session_refill between polls) ---------------
+namespace {
+struct ContinuousJob {
+    int n_utt = 0, slots = 0, poll = 16;
+    std::vector<int32_t> mx;                 // token limit of each utterance (without Turbo's extra first token)
+    std::function<int(int first, int count)> begin;                                                       // session with utterances [first, first + count)
+    std::function<int(const std::vector<int32_t>& slots, const std::vector<int32_t>& items)> refill;      // slots[i] takes utterance items[i]
+};
+
+int run_continuous(t3mi_model* m, const ContinuousJob& job, int32_t* out, int32_t cap, int32_t* n_out, int32_t* stats) {
+    const int extra = m->variant == T3MI_VARIANT_TURBO ? 1 : 0;
+    int rc = job.begin(0, job.slots);
+    if (rc) return rc;
+    Session* s = m->sess.get();
+    const int drop_from = s->prm.drop_invalid_from;
+    std::vector<int32_t> owner(job.slots), ntok(job.slots), done(job.slots), buf((size_t)s->cap);
+    for (int u = 0; u < job.slots; ++u) owner[u] = u;
+    int next = job.slots, live = job.slots, warn = T3MI_OK;
+    long long steps = 0, refills = 0, busy = 0;
+    while (live > 0 && !rc) {
+        if ((rc = t3mi_session_decode(m, job.poll))) break;
+        steps += job.poll;
+        busy += (long long)job.poll * live;
+        if ((rc = t3mi_session_status(m, ntok.data(), done.data()))) break;
+        std::vector<int32_t> freed;
+        for (int u = 0; u < job.slots && !rc; ++u) {
+            const int i = owner[u];
+            if (i < 0 || !(done[u] != 0 || ntok[u] >= job.mx[i] + extra)) continue;
+            int32_t n = 0;
+            if ((rc = t3mi_session_tokens(m, u, buf.data(), (int32_t)buf.size(), &n))) break;
+            n = std::min(n, job.mx[i] + extra);
+            int32_t k = 0;
+            int32_t* dst = out + (size_t)i * cap;
+            for (int32_t j = 0; j < n && k < cap; ++j)
+                if (drop_from <= 0 || buf[j] < drop_from) dst[k++] = buf[j];   // drop_invalid_tokens (R/s3tokenizer.R:678-687)
+            n_out[i] = k;
+            if (done[u] == 3) warn = T3MI_WARN_CACHE_FULL;
+            owner[u] = -1;
+            --live;
+            freed.push_back(u);
+        }
+        if (rc) break;
+        const int take = std::min<int>((int)freed.size(), job.n_utt - next);
+        if (take > 0) {
+            std::vector<int32_t> sl(freed.begin(), freed.begin() + take), it(take);
+            for (int k = 0; k < take; ++k) { it[k] = next + k; owner[sl[k]] = next + k; }
+            if ((rc = job.refill(sl, it))) break;
+            next += take;
+            live += take;
+            ++refills;
+        }
+    }
+    if (stats) {
+        stats[0] = (int32_t)std::min<long long>(steps, 0x7FFFFFFF);
+        stats[1] = (int32_t)refills;
+        stats[2] = (int32_t)std::min<long long>(busy, 0x7FFFFFFF);
+        stats[3] = job.slots;
+    }
+    std::string keep = g_err;
+    t3mi_session_end(m);
+    if (rc) {
+        g_err = keep;
+        return rc;
+    }
+    if (warn) g_err = "KV cache full, generation stopped (src/t3_decode.cpp:394-397)";
+    return warn;
+}
+
+// common argument checks; fills job.mx and the session parameters (cache rows long enough for every utterance that may come)
+int continuous_setup(t3mi_model* m, int n_utt, const int32_t* s0, const int32_t* max_new_each, int slots, int poll_steps,
+                     const t3mi_params* p, int32_t cap, ContinuousJob& job, t3mi_params& sp) {
+    if (!m || !p || n_utt <= 0) return fail(T3MI_ERR_ARG, "t3mi_generate_continuous: null or empty argument");
+    if (slots <= 0 || poll_steps <= 0) return fail(T3MI_ERR_ARG, "t3mi_generate_continuous: slots and poll_steps must be positive");
+    const int extra = m->variant == T3MI_VARIANT_TURBO ? 1 : 0;
+    job.n_utt = n_utt;
+    job.slots = std::min(slots, n_utt);
+    job.poll = poll_steps;
+    job.mx.resize(n_utt);
+    int top = 0, need = 0;
+    for (int i = 0; i < n_utt; ++i) {
+        const int v = max_new_each ? max_new_each[i] : p->max_new_tokens;
+        if (v <= 0 || v > p->max_new_tokens) return fail(T3MI_ERR_ARG, "t3mi_generate_continuous: every token limit must be in 1..max_new_tokens");
+        job.mx[i] = v;
+        top = std::max(top, v);
+        need = std::max(need, s0[i] + v);
+    }
+    if (cap < top + extra) return fail(T3MI_ERR_ARG, "output capacity is smaller than the largest token limit");
+    sp = *p;
+    sp.max_new_tokens = top;
+    if (sp.max_cache_len <= 0) sp.max_cache_len = need + 2 + extra;   // long enough that the per-row clamp of R/t3.R:996 never binds
+    return T3MI_OK;
+}
+}  // namespace
+
+int t3mi_generate_continuous(t3mi_model* m, int n_utt, int rows_per_utt, const float* const* embeds, const int32_t* s0,
+                             const int32_t* max_new_each, int slots, int poll_steps, const t3mi_params* p, int32_t* out,
+                             int32_t cap, int32_t* n_out, int32_t* stats) {
+    if (!embeds || !s0 || !out || !n_out) return fail(T3MI_ERR_ARG, "t3mi_generate_continuous: null argument");
+    ContinuousJob job;
+    t3mi_params sp;
+    int rc = continuous_setup(m, n_utt, s0, max_new_each, slots, poll_steps, p, cap, job, sp);
+    if (rc) return rc;
+    job.begin = [&](int first, int count) { return t3mi_session_begin(m, count, rows_per_utt, embeds + first, s0 + first, &sp, 0); };
+    job.refill = [&](const std::vector<int32_t>& sl, const std::vector<int32_t>& it) {
+        std::vector<const float*> e(it.size());
+        std::vector<int32_t> l(it.size()), mn(it.size());
+        std::vector<int64_t> id(it.size());
+        for (size_t k = 0; k < it.size(); ++k) {
+            e[k] = embeds[it[k]]; l[k] = s0[it[k]]; mn[k] = job.mx[it[k]];
+            id[k] = (int64_t)sp.first_utterance_id + it[k];
+        }
+        return t3mi_session_refill(m, (int)it.size(), sl.data(), e.data(), l.data(), mn.data(), id.data(), 0);
+    };
+    return run_continuous(m, job, out, cap, n_out, stats);
+}
+
+int t3mi_generate_continuous_tokens(t3mi_model* m, int n_utt, const t3mi_cond* conds, const int32_t* const* text_tokens,
+                                    const int32_t* n_text, const int32_t* max_new_each, int slots, int poll_steps,
+                                    const t3mi_params* p, int32_t* out, int32_t cap, int32_t* n_out, int32_t* stats) {
+    if (!m || !p || !conds || !text_tokens || !n_text || !out || !n_out || n_utt <= 0)
+        return fail(T3MI_ERR_ARG, "t3mi_generate_continuous_tokens: null or empty argument");
+    std::vector<int32_t> s0(n_utt);
+    {
+        const t3mi::PromptEnv env = prompt_env(m, p->start_token);
+        std::string err;
+        for (int i = 0; i < n_utt; ++i) {
+            int r = 0, lc = 0, l = 0;
+            const int rc = t3mi::prompt_shape(m->prompt, env, prompt_cond(&conds[i]), n_text[i], p->cfg_weight, &r, &l, &lc, err);
+            if (rc) return fail(rc, "utterance " + std::to_string(i) + ": " + err);
+            s0[i] = l;
+        }
+    }
+    ContinuousJob job;
+    t3mi_params sp;
+    int rc = continuous_setup(m, n_utt, s0.data(), max_new_each, slots, poll_steps, p, cap, job, sp);
+    if (rc) return rc;
+    job.begin = [&](int first, int count) { return t3mi_session_begin_tokens(m, count, conds + first, text_tokens + first, n_text + first, &sp); };
+    job.refill = [&](const std::vector<int32_t>& sl, const std::vector<int32_t>& it) {
+        std::vector<t3mi_cond> c(it.size());
+        std::vector<const int32_t*> t(it.size());
+        std::vector<int32_t> nt(it.size()), mn(it.size());
+        std::vector<int64_t> id(it.size());
+        for (size_t k = 0; k < it.size(); ++k) {
+            c[k] = conds[it[k]]; t[k] = text_tokens[it[k]]; nt[k] = n_text[it[k]]; mn[k] = job.mx[it[k]];
+            id[k] = (int64_t)sp.first_utterance_id + it[k];
+        }
+        return t3mi_session_refill_tokens(m, (int)it.size(), sl.data(), c.data(), t.data(), nt.data(), mn.data(), id.data());
+    };
+    return run_continuous(m, job, out, cap, n_out, stats);
 }
 
 int t3mi_generate_batch_tokens(t3mi_model* m, int n_utt, const t3mi_cond* conds, const int32_t* const* text_tokens,

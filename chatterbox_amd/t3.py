@@ -426,13 +426,26 @@ class Session:
                  min_p: float = 0.05, repetition_penalty: float = 1.2, sampler: int = _lib.SAMPLER_R,
                  max_cache_len: int = 0, seed: int = 0, mask_stop: bool = False,
                  forced: Optional[np.ndarray] = None, device_ptrs: Optional[Sequence[Tuple[int, int]]] = None,
-                 top_k: int = 0, first_utterance_id: int = 0):
+                 top_k: int = 0, first_utterance_id: int = 0, text_tokens_list: Optional[Sequence] = None):
         self.model = model
         L = model._lib
         if model.variant == _lib.VARIANT_TURBO:
             sampler, cfg_weight, min_p = _lib.SAMPLER_TURBO, 0.0, 0.0
         p = _params(model, max_new_tokens, temperature, cfg_weight, top_p, min_p, repetition_penalty,
                     sampler, max_cache_len, seed, mask_stop, top_k, first_utterance_id)
+        self.cfg_weight = float(cfg_weight)
+        if text_tokens_list is not None:
+            # embeds_list holds T3Cond objects: the prompts are built on the device (t3mi_session_begin_tokens)
+            conds, tts = list(embeds_list), [_text(t) for t in text_tokens_list]
+            self.n_utt = len(conds)
+            self.rpu = 2 if (cfg_weight > 0 and model.variant != _lib.VARIANT_TURBO) else 1
+            cs = (_lib.Cond * self.n_utt)(*[c.c_struct() for c in conds])
+            tp = (C.POINTER(C.c_int32) * self.n_utt)(*[t.ctypes.data_as(C.POINTER(C.c_int32)) for t in tts])
+            nt = (C.c_int32 * self.n_utt)(*[t.size for t in tts])
+            self._keep = (conds, tts)
+            _lib.check(L.t3mi_session_begin_tokens(model._h, self.n_utt, cs, tp, nt, C.byref(p)))
+            self.max_new_tokens = int(max_new_tokens) + (1 if model.variant == _lib.VARIANT_TURBO else 0)
+            return
         if device_ptrs is not None:
             # [(device_address, s0)] of prompts already resident in HBM, each [rpu, s0, d] float32
             self.n_utt = len(device_ptrs)
@@ -453,6 +466,30 @@ class Session:
         if forced is not None:
             f = np.ascontiguousarray(forced, dtype=np.int32).reshape(self.n_utt, -1)
             _lib.check(L.t3mi_session_force(model._h, f.ctypes.data_as(C.POINTER(C.c_int32)), f.shape[1]))
+
+    def refill(self, utts: Sequence[int], embeds_list: Sequence, text_tokens_list: Optional[Sequence] = None,
+               max_new_tokens: Optional[Sequence[int]] = None, utterance_ids: Optional[Sequence[int]] = None) -> None:
+        """Continuous batching (t3mi_session_refill): slots `utts` take new utterances -- prompt embeddings [rows, S0, d], or T3Cond
+        objects with `text_tokens_list` -- while the other slots keep decoding from where they are.  Read a finished slot's
+        tokens() first.  `max_new_tokens[i]`: the utterance's own limit (at most the session's); `utterance_ids[i]`: the global
+        index that names its random stream (default: first_utterance_id + slot)."""
+        L, n = self.model._lib, len(utts)
+        ua = (C.c_int32 * n)(*[int(u) for u in utts])
+        mn = (C.c_int32 * n)(*[int(v) for v in max_new_tokens]) if max_new_tokens is not None else None
+        ids = (C.c_int64 * n)(*[int(v) for v in utterance_ids]) if utterance_ids is not None else None
+        if text_tokens_list is not None:
+            conds, tts = list(embeds_list), [_text(t) for t in text_tokens_list]
+            cs = (_lib.Cond * n)(*[c.c_struct() for c in conds])
+            tp = (C.POINTER(C.c_int32) * n)(*[t.ctypes.data_as(C.POINTER(C.c_int32)) for t in tts])
+            nt = (C.c_int32 * n)(*[t.size for t in tts])
+            _lib.check(L.t3mi_session_refill_tokens(self.model._h, n, ua, cs, tp, nt, mn, ids))
+            return
+        es = [_as_embeds(self.model, e, self.cfg_weight) for e in embeds_list]
+        if any(e.shape[0] != self.rpu for e in es):
+            raise ValueError(f"refill: every prompt needs {self.rpu} row(s) like the session's utterances")
+        ptrs = (C.c_void_p * n)(*[e.ctypes.data for e in es])
+        s0 = (C.c_int32 * n)(*[e.shape[1] for e in es])
+        _lib.check(L.t3mi_session_refill(self.model._h, n, ua, ptrs, s0, mn, ids, 0))
 
     def decode(self, n_steps: int = 1):
         _lib.check(self.model._lib.t3mi_session_decode(self.model._h, int(n_steps)))
@@ -532,3 +569,64 @@ class Session:
 
     def __exit__(self, *exc):
         self.end()
+
+
+def prompt_length(model: T3Model, cond: T3Cond, n_text: int, cfg_weight: float = 0.5) -> int:
+    """Positions of the prompt prepare_input_embeds builds for this conditioning and text length (t3mi_prompt_shape)."""
+    rows, s0, lc = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    c = cond.c_struct()
+    _lib.check(model._lib.t3mi_prompt_shape(model._h, C.byref(c), int(n_text), float(cfg_weight), C.byref(rows), C.byref(s0), C.byref(lc)))
+    return int(s0.value)
+
+
+def t3_inference_continuous(model: T3Model, embeds_list: Sequence, text_tokens_list: Optional[Sequence] = None,
+                            slots: int = 64, poll_steps: int = 16, max_new_tokens=1000,
+                            temperature: float = 0.8, cfg_weight: float = 0.5, top_p: float = 0.95, min_p: float = 0.05,
+                            repetition_penalty: float = 1.2, top_k: int = 1000, seed: Optional[int] = None, mask_stop: bool = False,
+                            first_utterance_id: int = 0, drop_invalid=None, stats: Optional[dict] = None) -> List[np.ndarray]:
+    """Any number of utterances through `slots` batch slots that never idle: every `poll_steps` decode steps the slots whose
+    utterance has ended (stop token, its own `max_new_tokens[i]`, cache full) hand their tokens back and take the next waiting
+    utterances, prefilled together (t3mi_generate_continuous over t3mi_session_refill) while the others keep their caches.  The reference decodes sentences one after
+    the other (tts_chunked, R/tts.R:466-474); a fixed batch (t3_inference_batch) runs until its LONGEST utterance ends.
+    Per-utterance semantics, argument forms and random streams are those of t3_inference_batch / t3_inference_turbo_batch
+    (utterance i draws from stream (seed, first_utterance_id + i) wherever it runs), so with fp32 weights the tokens are the
+    batch call's.  `max_new_tokens`: one int or one per utterance.  `stats` (optional dict) receives steps, refill calls and
+    the slot occupancy."""
+    n = len(embeds_list)
+    if n == 0:
+        return []
+    turbo = model.variant == _lib.VARIANT_TURBO
+    if turbo:
+        cfg_weight, min_p, sampler = 0.0, 0.0, _lib.SAMPLER_TURBO
+    else:
+        top_k, sampler = 0, _lib.SAMPLER_R
+    mx = [int(max_new_tokens)] * n if np.isscalar(max_new_tokens) else [int(v) for v in max_new_tokens]
+    if len(mx) != n or min(mx) <= 0:
+        raise ValueError("max_new_tokens: one positive int, or one per utterance")
+    p = _params(model, max(mx), temperature, cfg_weight, top_p, min_p, repetition_penalty, sampler, 0, seed, mask_stop, top_k,
+                first_utterance_id=first_utterance_id, drop_invalid=drop_invalid)
+    cap = max(mx) + (1 if turbo else 0)       # Turbo's first token comes from the prefill logits (R/t3.R:1614-1658)
+    out = np.zeros((n, cap), dtype=np.int32)
+    n_out = (C.c_int32 * n)()
+    lim = (C.c_int32 * n)(*mx)
+    st = (C.c_int32 * 4)()
+    L = model._lib
+    if text_tokens_list is not None:          # embeds_list holds T3Cond objects, one per utterance
+        conds, tts = list(embeds_list), [_text(t) for t in text_tokens_list]
+        cs = (_lib.Cond * n)(*[c.c_struct() for c in conds])
+        tp = (C.POINTER(C.c_int32) * n)(*[t.ctypes.data_as(C.POINTER(C.c_int32)) for t in tts])
+        nt = (C.c_int32 * n)(*[t.size for t in tts])
+        rc = _lib.check(L.t3mi_generate_continuous_tokens(model._h, n, cs, tp, nt, lim, int(slots), int(poll_steps), C.byref(p),
+                                                          out.ctypes.data_as(C.POINTER(C.c_int32)), cap, n_out, st))
+    else:
+        es = [_as_embeds(model, e, cfg_weight) for e in embeds_list]
+        ptrs = (C.c_void_p * n)(*[e.ctypes.data for e in es])
+        s0 = (C.c_int32 * n)(*[e.shape[1] for e in es])
+        rc = _lib.check(L.t3mi_generate_continuous(model._h, n, es[0].shape[0], ptrs, s0, lim, int(slots), int(poll_steps), C.byref(p),
+                                                   out.ctypes.data_as(C.POINTER(C.c_int32)), cap, n_out, st))
+    if rc == _lib.WARN_CACHE_FULL:
+        import warnings
+        warnings.warn("KV cache full, stopping generation")       # src/t3_decode.cpp:395
+    if stats is not None:
+        stats.update(steps=int(st[0]), refill_calls=int(st[1]), slots=int(st[3]), occupancy=st[2] / max(1, st[0] * st[3]))
+    return [out[u, : n_out[u]].astype(np.int64) for u in range(n)]

@@ -201,6 +201,33 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rows_per_utt, const float* 
 /* Teacher forcing (parity hook): utterance u emits forced[u*n_forced + i] at step i instead of
  * its own sample.  Call between session_begin and the first session_decode. */
 int t3mi_session_force(t3mi_model* m, const int32_t* forced, int n_forced);
+/* Continuous batching: slots utts[0..n) of the running session take new utterances while the other slots keep their state (cache rows,
+ * tokens, pending logits).  The reference has no counterpart: its tts_chunked runs the sentences one after the other (R/tts.R:466-474),
+ * and a fixed batch idles every slot whose sentence has ended ("refill from a host queue").  embeds[i] is the
+ * [rows_per_utt, s0[i], d] prompt of the utterance for slot utts[i] (as in t3mi_session_begin); max_new_tokens[i] its own token limit
+ * (NULL: the session's; never above it); utterance_ids[i] the global index that names its random stream (NULL: first_utterance_id +
+ * slot) -- with the id it would have had in one big batch, a refilled utterance draws the same tokens.  The prompt plus one token must
+ * fit the cache rows the session was begun with.  Waits for the enqueued steps, so read a finished slot's tokens BEFORE refilling it;
+ * the new prompts are prefilled together and the call returns with every slot's first logits pending.  Not available on a
+ * teacher-forced session or with T3MI_PREFILL=token. */
+int t3mi_session_refill(t3mi_model* m, int n, const int32_t* utts, const float* const* embeds, const int32_t* s0,
+                        const int32_t* max_new_tokens, const int64_t* utterance_ids, int embeds_on_device);
+/* The same with the prompts built on device from conditioning and text ids (prepare_input_embeds, R/t3.R:372-403). */
+int t3mi_session_refill_tokens(t3mi_model* m, int n, const int32_t* utts, const t3mi_cond* conds,
+                               const int32_t* const* text_tokens, const int32_t* n_text, const int32_t* max_new_tokens,
+                               const int64_t* utterance_ids);
+/* The whole job on top of t3mi_session_refill: n_utt utterances through `slots` batch slots; every `poll_steps` decode steps the slots
+ * whose utterance has ended (stop token, its own limit max_new_each[i] <= p->max_new_tokens, cache full) deliver their tokens and take the
+ * next waiting utterances.  Per-utterance results, status codes and the out / n_out layout are those of t3mi_generate_batch /
+ * t3mi_generate_batch_tokens (utterance i draws from stream (seed, first_utterance_id + i) wherever it runs); max_new_each may be
+ * NULL.  With p->max_cache_len = 0 the cache rows are sized for the longest prompt + limit of the job.  stats (may be NULL) receives
+ * {decode steps, refill calls, sum over steps of occupied slots, slots}.  Replaces the serial loop of tts_chunked (R/tts.R:466-474). */
+int t3mi_generate_continuous(t3mi_model* m, int n_utt, int rows_per_utt, const float* const* embeds, const int32_t* s0,
+                             const int32_t* max_new_each, int slots, int poll_steps, const t3mi_params* p, int32_t* out,
+                             int32_t cap, int32_t* n_out, int32_t* stats);
+int t3mi_generate_continuous_tokens(t3mi_model* m, int n_utt, const t3mi_cond* conds, const int32_t* const* text_tokens,
+                                    const int32_t* n_text, const int32_t* max_new_each, int slots, int poll_steps,
+                                    const t3mi_params* p, int32_t* out, int32_t cap, int32_t* n_out, int32_t* stats);
 /* Enqueue `n_steps` decode steps (one token per live utterance per step) on the model's
  * stream; returns without waiting. */
 int t3mi_session_decode(t3mi_model* m, int n_steps);
