@@ -376,7 +376,7 @@ def split_sentences(text: str) -> List[str]:
 
 
 def tts_chunked(model: T3Model, text: str, cond: T3Cond, tokenize, chunk_size: int = 200, batched: bool = True,
-                drop_invalid: bool = True, s3gen=None, ref_dict: Optional[dict] = None, **kw) -> dict:
+                drop_invalid: bool = True, s3gen=None, ref_dict: Optional[dict] = None, slots: Optional[int] = None, **kw) -> dict:
     """tts_chunked (R/tts.R:455-480) up to the speech tokens: the text is split into sentences exactly as the
     reference does, every sentence is tokenised by `tokenize(sentence) -> text token ids` (the reference's BPE
     tokenizer, or punc_norm + the GPT-2 tokenizer on Turbo: R/tts.R:278-285 -- host string work, out of scope
@@ -386,7 +386,8 @@ def tts_chunked(model: T3Model, text: str, cond: T3Cond, tokenize, chunk_size: i
     run the same kernel regime (greedy fp32: identical to the oracle in both, test_tts_chunked_batch_equals_serial),
     otherwise a draw within rounding of a CDF step may differ (8 rows run MFMA GEMMs, 2 rows GEMVs: other summation
     order).  `chunk_size` is accepted
-    and unused, as in the reference.  Keyword arguments are those of t3_inference / t3_inference_turbo
+    and unused, as in the reference.  `slots`: the batched order through that many slots with continuous batching
+    (t3_inference_continuous), for long texts whose sentences differ much in length.  Keyword arguments are those of t3_inference / t3_inference_turbo
     (generate() passes cfg_weight, temperature, top_p, and top_k / repetition_penalty on Turbo: R/tts.R:303-360).
     Returns {"sentences": [...], "speech_tokens": [array per sentence]} with drop_invalid_tokens applied
     (R/tts.R:366).  With `s3gen` (one (flow, vocoder) pair of chatterbox_amd.s3gen, or a list of pairs) and the voice's
@@ -401,7 +402,12 @@ def tts_chunked(model: T3Model, text: str, cond: T3Cond, tokenize, chunk_size: i
     fn = t3_inference_turbo_batch if turbo else t3_inference_batch
     # drop_invalid_tokens runs on the device at the end of the generate call (t3mi_params.drop_invalid_from)
     di = (drop_invalid if drop_invalid is not True else SPEECH_VOCAB_SIZE) if drop_invalid else None
-    if batched:
+    if batched and slots:
+        # continuous batching: the sentences go through `slots` batch slots, a slot takes the next sentence when its own has ended
+        out = t3_inference_continuous(model, [cond] * len(sentences), toks, slots=int(slots), drop_invalid=di, **kw)
+        if turbo:      # per-sentence semantics of t3_inference_turbo: the trailing stop token is removed (R/t3.R:1667-1671)
+            out = [t[:-1] if t.size and t[-1] == model.stop_speech_token else t for t in out]
+    elif batched:
         out = fn(model, [cond] * len(sentences), toks, drop_invalid=di, **kw)
     else:
         out = [fn(model, [cond], [t], first_utterance_id=i, drop_invalid=di, **kw)[0] for i, t in enumerate(toks)]

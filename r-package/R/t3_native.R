@@ -170,12 +170,26 @@ t3_inference_turbo <- function (model, cond, text_tokens, max_new_tokens = 1000,
     else torch::torch_tensor(integer(0), device = device)
 }
 
+# the continuous-batching entries of the config list (read by t3mi_r_generate_tokens / t3mi_r_generate_batch)
+.t3mi_continuous <- function (cfg, slots, each, poll_steps, n)
+{
+    if (is.null(slots) && is.null(each)) return(cfg)
+    if (!is.null(each) && length(each) != n) stop("max_new_tokens_each needs one entry per utterance")
+    cfg$slots <- as.integer(if (is.null(slots)) n else slots)
+    cfg$poll_steps <- as.integer(poll_steps)
+    if (!is.null(each)) cfg$max_tokens_each <- as.integer(each)
+    cfg
+}
+
 #' Many utterances at once (the batch axis tts_chunked leaves serial, R/tts.R:462-474): `conds` and
 #' `text_tokens_list` are lists of the per-sentence arguments of t3_inference; returns a list of token tensors.
+#' `slots`: continuous batching (t3mi_generate_continuous) -- the utterances go through that many batch slots and a slot takes the
+#' next waiting utterance as soon as its own has ended, instead of one batch that runs until its longest utterance ends;
+#' `max_new_tokens_each`: one limit per utterance (at most max_new_tokens).  Utterance i draws from the stream (seed, i) either way.
 t3_inference_batch <- function (model, conds, text_tokens_list, max_new_tokens = 1000,
                                 temperature = 0.8, cfg_weight = 0.5, top_p = 0.95,
                                 min_p = 0.05, repetition_penalty = 1.2,
-                                native = t3mi_model(), seed = NULL)
+                                native = t3mi_model(), seed = NULL, slots = NULL, max_new_tokens_each = NULL, poll_steps = 16L)
 {
     config <- model$config
     device <- model$text_emb$weight$device
@@ -184,6 +198,7 @@ t3_inference_batch <- function (model, conds, text_tokens_list, max_new_tokens =
                 rep_penalty = as.double(repetition_penalty), sampler = 0L, seed = .t3mi_seed(seed),
                 start_token = as.integer(config$start_speech_token),
                 stop_token = as.integer(config$stop_speech_token))
+    cfg <- .t3mi_continuous(cfg, slots, max_new_tokens_each, poll_steps, length(conds))
     ids <- .Call("t3mi_r_generate_tokens", native, lapply(conds, .t3mi_cond),
                  lapply(text_tokens_list, function (t) as.integer(t$cpu())), cfg, PACKAGE = "chatterbox")
     lapply(ids, function (v) torch::torch_tensor(v, dtype = torch::torch_long(), device = device))
@@ -192,7 +207,8 @@ t3_inference_batch <- function (model, conds, text_tokens_list, max_new_tokens =
 #' Turbo counterpart of t3_inference_batch: per-sentence semantics of t3_inference_turbo (trailing stop token removed).
 t3_inference_turbo_batch <- function (model, conds, text_tokens_list, max_new_tokens = 1000,
                                       temperature = 0.8, top_k = 1000L, top_p = 0.95, repetition_penalty = 1.2,
-                                      native = t3mi_model(variant = "turbo"), seed = NULL)
+                                      native = t3mi_model(variant = "turbo"), seed = NULL, slots = NULL,
+                                      max_new_tokens_each = NULL, poll_steps = 16L)
 {
     config <- model$config
     device <- model$speech_emb$weight$device
@@ -201,6 +217,7 @@ t3_inference_turbo_batch <- function (model, conds, text_tokens_list, max_new_to
                 rep_penalty = as.double(repetition_penalty), sampler = 2L, seed = .t3mi_seed(seed),
                 start_token = as.integer(config$start_speech_token),
                 stop_token = as.integer(config$stop_speech_token))
+    cfg <- .t3mi_continuous(cfg, slots, max_new_tokens_each, poll_steps, length(conds))
     ids <- .Call("t3mi_r_generate_tokens", native, lapply(conds, .t3mi_cond),
                  lapply(text_tokens_list, function (t) as.integer(t$cpu())), cfg, PACKAGE = "chatterbox")
     lapply(ids, function (v) {
@@ -232,7 +249,9 @@ tts_chunked <- function (model, text, voice, chunk_size = 200, exaggeration = 0.
                          repetition_penalty = 1.2, seed = NULL, devices = 0L,
                          native = t3mi_model(variant = if (isTRUE(model$turbo)) "turbo" else "llama",
                                              device = devices[1L]),
-                         s3gen_native = NULL)      # t3mi_s3gen() (R/s3gen_native.R): the waveform side on the MI355X as well
+                         s3gen_native = NULL,      # t3mi_s3gen() (R/s3gen_native.R): the waveform side on the MI355X as well
+                         slots = NULL)             # batch slots of t3_inference_batch (continuous batching): long texts with sentences of
+                                                   # very different length keep every slot busy; NULL = all sentences in one batch
 {
     if (!is_loaded(model)) stop("Model not loaded. Call load_chatterbox() first.")
     sentences <- strsplit(text, "(?<=[.!?])\\s+", perl = TRUE)[[1]]
@@ -257,10 +276,10 @@ tts_chunked <- function (model, text, voice, chunk_size = 200, exaggeration = 0.
                              repetition_penalty = repetition_penalty)
     else if (is_turbo)
         t3_inference_turbo_batch(model$t3, conds, toks, temperature = temperature, top_k = top_k, top_p = top_p,
-                                 repetition_penalty = repetition_penalty, native = native, seed = seed)
+                                 repetition_penalty = repetition_penalty, native = native, seed = seed, slots = slots)
     else
         t3_inference_batch(model$t3, conds, toks, cfg_weight = cfg_weight, temperature = temperature, top_p = top_p,
-                           native = native, seed = seed)
+                           native = native, seed = seed, slots = slots)
     all_audio <- numeric(0)
     for (i in seq_along(sentences)) {
         tk <- drop_invalid_tokens(speech[[i]])

@@ -41,6 +41,21 @@ static double cfg_real(SEXP list, const char* name, double dflt, int required) {
     return dflt;
 }
 
+/* optional integer-vector entry of the config list (max_tokens_each); NULL when absent.  *n receives its length. */
+static const int* cfg_ints(SEXP list, const char* name, int* n) {
+    SEXP names = Rf_getAttrib(list, R_NamesSymbol);
+    *n = 0;
+    if (TYPEOF(list) != VECSXP || names == R_NilValue) return NULL;
+    for (R_xlen_t i = 0; i < Rf_xlength(list); i++)
+        if (strcmp(CHAR(STRING_ELT(names, i)), name) == 0) {
+            SEXP v = VECTOR_ELT(list, i);
+            if (!Rf_isInteger(v)) return NULL;
+            *n = (int)Rf_xlength(v);
+            return INTEGER(v);
+        }
+    return NULL;
+}
+
 static void model_finalizer(SEXP ptr) {
     t3mi_model* m = (t3mi_model*)R_ExternalPtrAddr(ptr);
     if (m) {
@@ -161,9 +176,17 @@ SEXP t3mi_r_generate_batch(SEXP model, SEXP embeds_list, SEXP dims, SEXP cfg) {
         e[u] = to_row_major(VECTOR_ELT(embeds_list, u), rows, s0[u], d);
         if (!e[u]) rc = T3MI_ERR_ARG;   /* wrong shape / out of memory: everything is freed below before Rf_error */
     }
+    /* slots > 0 in the config: continuous batching (t3mi_generate_continuous) -- the utterances go through that many batch slots,
+     * a slot takes the next one as soon as its own has ended; max_tokens_each (integer, one per utterance) are their own limits */
+    const int slots = (int)cfg_real(cfg, "slots", 0, 0), poll = (int)cfg_real(cfg, "poll_steps", 16, 0);
+    int n_each = 0;
+    const int* each = cfg_ints(cfg, "max_tokens_each", &n_each);
+    if (rc == T3MI_OK && each && n_each != n_utt) rc = T3MI_ERR_ARG;
     const int bad_args = rc != T3MI_OK;   /* refused here (shapes, memory), as opposed to refused by the library */
-    if (rc == T3MI_OK)
-        rc = t3mi_generate_batch(m, n_utt, rows, (const float* const*)e, s0, &p, out, cap, n_out);
+    if (rc == T3MI_OK) {
+        if (slots > 0) rc = t3mi_generate_continuous(m, n_utt, rows, (const float* const*)e, s0, (const int32_t*)each, slots, poll, &p, out, cap, n_out, NULL);
+        else rc = t3mi_generate_batch(m, n_utt, rows, (const float* const*)e, s0, &p, out, cap, n_out);
+    }
     if (e) for (int u = 0; u < n_utt; u++) free(e[u]);
     free(e);
     free(s0);
@@ -251,8 +274,15 @@ SEXP t3mi_r_generate_tokens(SEXP model, SEXP conds, SEXP texts, SEXP cfg) {
         if (!fill_cond(VECTOR_ELT(conds, u), VECTOR_ELT(texts, u), &c[u], &h[u], &nt[u])) rc = T3MI_ERR_ARG;
         tp[u] = h[u].text;
     }
+    const int slots = (int)cfg_real(cfg, "slots", 0, 0), poll = (int)cfg_real(cfg, "poll_steps", 16, 0);   /* as in t3mi_r_generate_batch */
+    int n_each = 0;
+    const int* each = cfg_ints(cfg, "max_tokens_each", &n_each);
+    if (rc == T3MI_OK && each && n_each != n_utt) rc = T3MI_ERR_ARG;
     const int bad_args = rc != T3MI_OK;
-    if (rc == T3MI_OK) rc = t3mi_generate_batch_tokens(m, n_utt, c, tp, nt, &p, out, cap, n_out);
+    if (rc == T3MI_OK) {
+        if (slots > 0) rc = t3mi_generate_continuous_tokens(m, n_utt, c, tp, nt, (const int32_t*)each, slots, poll, &p, out, cap, n_out, NULL);
+        else rc = t3mi_generate_batch_tokens(m, n_utt, c, tp, nt, &p, out, cap, n_out);
+    }
     free(c);
     free_hold(h, n_utt);
     free((void*)tp);

@@ -129,6 +129,8 @@ static DL_FUNC find_call(const char* name, int nargs) {
 typedef struct {
     int max_tokens, sampler, top_k, max_cache_len, start_token, stop_token, omit_required;
     double temperature, cfg_weight, top_p, min_p, rep_penalty, seed;
+    int slots, poll_steps, n_each;          /* slots > 0: continuous batching; n_each > 0: max_tokens_each follows */
+    const int32_t* each;
 } mock_cfg;
 static SEXP mk_cfg(const mock_cfg* c) {
     static const char* const nm[] = {"max_tokens", "temperature", "cfg_weight", "top_p", "min_p", "rep_penalty", "stop_token",
@@ -138,6 +140,17 @@ static SEXP mk_cfg(const mock_cfg* c) {
     SEXP v[12] = {mk_int1(c->max_tokens), mk_real1(c->temperature), mk_real1(c->cfg_weight), mk_real1(c->top_p), mk_real1(c->min_p),
                   mk_real1(c->rep_penalty), mk_int1(c->stop_token), mk_int1(c->start_token), mk_int1(c->sampler), mk_int1(c->top_k),
                   mk_int1(c->max_cache_len), mk_real1(c->seed)};
+    if (!c->omit_required && c->slots > 0) {
+        static const char* const nx[] = {"max_tokens", "temperature", "cfg_weight", "top_p", "min_p", "rep_penalty", "stop_token",
+                                         "start_token", "sampler", "top_k", "max_cache_len", "seed", "slots", "poll_steps", "max_tokens_each"};
+        const int nn = c->n_each > 0 ? 15 : 14;
+        SEXP lx = Rf_allocVector(VECSXP, nn);
+        for (int i = 0; i < 12; i++) SET_VECTOR_ELT(lx, i, v[i]);
+        SET_VECTOR_ELT(lx, 12, mk_int1(c->slots));
+        SET_VECTOR_ELT(lx, 13, mk_int1(c->poll_steps));
+        if (c->n_each > 0) SET_VECTOR_ELT(lx, 14, mk_int(c->each, c->n_each));
+        return mk_names(lx, nx);
+    }
     for (int i = 0; i < n; i++) SET_VECTOR_ELT(l, i, v[i]);
     return mk_names(l, nm);
 }

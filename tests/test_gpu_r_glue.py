@@ -19,7 +19,8 @@ LIB = os.path.join(HERE, "r_mock", "librglue_mock.so")
 
 class MockCfg(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("max_tokens", "sampler", "top_k", "max_cache_len", "start_token", "stop_token", "omit_required")] + \
-               [(n, C.c_double) for n in ("temperature", "cfg_weight", "top_p", "min_p", "rep_penalty", "seed")]
+               [(n, C.c_double) for n in ("temperature", "cfg_weight", "top_p", "min_p", "rep_penalty", "seed")] + \
+               [(n, C.c_int) for n in ("slots", "poll_steps", "n_each")] + [("each", C.POINTER(C.c_int32))]
 
 
 @pytest.fixture(scope="module")
@@ -200,3 +201,28 @@ def test_s3gen_through_the_glue_equals_the_ctypes_path():
     with cb.load_s3gen_flow(synth.ensure_flow_checkpoint(fd, 555)) as flow:
         assert rc == 0 and np.array_equal(mel3, flow.inference(t3, ptok, pfeat, xvec, z))
     assert lib.mock_protect_balance() == 0
+
+
+def test_continuous_batching_through_the_glue(glue):
+    """`slots` / `poll_steps` / `max_tokens_each` in the config list of t3mi_r_generate_tokens (what t3_inference_batch(..., slots =)
+    in R/t3_native.R passes): 7 utterances through 3 slots == the ctypes path == the one-call batch cut at each limit."""
+    lib, dims, model = glue
+    rng = np.random.default_rng(8)
+    n = 7
+    conds = [((rng.standard_normal(dims.speaker_embed) * 0.1).astype(np.float32), rng.integers(0, dims.start_speech_token, 15 + 5 * u), 0.5)
+             for u in range(n)]
+    texts = [rng.integers(1, 250, 3 + 2 * u) for u in range(n)]
+    lim = np.array([5, 12, 3, 9, 12, 7, 10], dtype=np.int32)
+    cfg = _cfg(dims, slots=3, poll_steps=4, n_each=n, each=lim.ctypes.data_as(C.POINTER(C.c_int32)))
+    rc, got = _tokens_call(lib, dims, conds, texts, cfg)
+    assert rc == 0, lib.mock_last_error()
+    assert lib.mock_protect_balance() == 0
+    cs = [cb.t3_cond(c[0], c[1], emotion_adv=c[2]) for c in conds]
+    want = cb.t3_inference_continuous(model, cs, texts, slots=3, poll_steps=4, max_new_tokens=list(lim), top_p=0.0, seed=0)
+    ref = cb.t3_inference_batch(model, cs, texts, max_new_tokens=12, top_p=0.0, seed=0)
+    for u in range(n):
+        assert got[u] == list(want[u]) == list(ref[u][: lim[u]]), (u, got[u], want[u], ref[u])
+    # a limit list of the wrong length is refused before the library is called
+    bad = _cfg(dims, slots=3, poll_steps=4, n_each=2, each=lim.ctypes.data_as(C.POINTER(C.c_int32)))
+    rc, _ = _tokens_call(lib, dims, conds, texts, bad)
+    assert rc == -1 and b"t3mi_generate_tokens" in lib.mock_last_error()

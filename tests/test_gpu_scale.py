@@ -346,6 +346,9 @@ def test_tts_chunked_batch_equals_serial():
             want = O.t3_inference(om, pe, O.SampleParams(max_new_tokens=16, top_p=0.0)).tokens
             assert list(gb["speech_tokens"][i]) == want, f"batched, sentence {i}"
             assert list(gs["speech_tokens"][i]) == want, f"serial, sentence {i}"
+        # and through two batch slots with continuous batching (sentences 3 and 4 take the slots the first two leave)
+        gc = cb.tts_chunked(model, text, cond, tokenize, drop_invalid=False, slots=2, poll_steps=4, **gk)
+        assert [list(t) for t in gc["speech_tokens"]] == [list(t) for t in gb["speech_tokens"]]
     finally:
         model.close()
 
