@@ -10,6 +10,7 @@ from .t3 import (SPEECH_VOCAB_SIZE, Session, T3Cond, T3Model, drop_invalid_token
                  t3_inference_traced, t3_inference_turbo, t3_inference_turbo_batch, tts_chunked)
 
 from .s3gen import (CfmEstimator, HiftVocoder, S3GenFlow, causal_cfm_forward, load_cfm_estimator, load_hift_vocoder,  # noqa: F401,E402
-                    load_s3gen_flow, s3gen_inference, synthesize)  # noqa: F401,E402
+                    load_s3gen_flow, s3gen_inference, synthesize, synthesize_one)  # noqa: F401,E402
+from .pipeline import tts_pipelined, tts_stream  # noqa: F401,E402
 
 __version__ = "0.1.0"

@@ -252,6 +252,24 @@ def s3gen_inference(flow: S3GenFlow, vocoder: HiftVocoder, speech_tokens, ref_di
 S3GEN_SIL = 4299      # silence token appended three times on Turbo (R/s3gen.R:6, R/tts.R:374-378)
 
 
+def synthesize_one(flow, voc, tokens, index: int, ref_dict: dict, seed: int, turbo: bool = False,
+                   n_cfm_timesteps: Optional[int] = None, timing: Optional[dict] = None) -> np.ndarray:
+    """One utterance of synthesize(): its draws (CFM start noise, harmonic start phases, source noise) come from the numpy generator
+    keyed by (seed, index), so the audio is the same whichever handle, thread or call produces it."""
+    t = np.asarray(tokens, dtype=np.int64).reshape(-1)
+    if t.size == 0:
+        return np.zeros(0, np.float32)
+    if turbo:
+        t = np.concatenate([t, np.full(3, S3GEN_SIL, t.dtype)])
+    n_prompt = int(np.reshape(ref_dict["prompt_token"], -1).size)
+    rng = np.random.Generator(np.random.PCG64([int(seed), int(index)]))
+    z = rng.standard_normal((1, flow.mel, 2 * (n_prompt + t.size)), dtype=np.float32)
+    phase = rng.uniform(-np.pi, np.pi, voc.n_harmonics).astype(np.float32)
+    snoise = rng.standard_normal((voc.n_harmonics, 2 * t.size * voc.samples_per_frame), dtype=np.float32)
+    audio, _ = s3gen_inference(flow, voc, t, ref_dict, z, phase, snoise, finalize=True, n_cfm_timesteps=n_cfm_timesteps, timing=timing)
+    return audio
+
+
 def synthesize(handles, token_lists: Sequence, ref_dict: dict, seed: Optional[int] = None, turbo: bool = False,
                n_cfm_timesteps: Optional[int] = None, timing: Optional[dict] = None) -> list:
     """The waveform half of generate() (R/tts.R:365-412) for several utterances of ONE voice: every token vector (already through
@@ -272,7 +290,6 @@ def synthesize(handles, token_lists: Sequence, ref_dict: dict, seed: Optional[in
     toks = [np.asarray(t, dtype=np.int64).reshape(-1) for t in token_lists]
     out: list = [None] * len(toks)
     times: list = [None] * len(toks)
-    n_prompt = int(np.reshape(ref_dict["prompt_token"], -1).size)
     steps = n_cfm_timesteps if n_cfm_timesteps is not None else (2 if turbo else None)
     errors: list = []
 
@@ -280,19 +297,8 @@ def synthesize(handles, token_lists: Sequence, ref_dict: dict, seed: Optional[in
         flow, voc = pairs[w]
         try:
             for u in range(w, len(toks), len(pairs)):
-                t = toks[u]
-                if t.size == 0:
-                    out[u] = np.zeros(0, np.float32)
-                    continue
-                if turbo:
-                    t = np.concatenate([t, np.full(3, S3GEN_SIL, t.dtype)])
-                rng = np.random.Generator(np.random.PCG64([int(seed), u]))
-                frames_all = 2 * (n_prompt + t.size)
-                z = rng.standard_normal((1, flow.mel, frames_all), dtype=np.float32)
-                phase = rng.uniform(-np.pi, np.pi, voc.n_harmonics).astype(np.float32)
-                snoise = rng.standard_normal((voc.n_harmonics, 2 * t.size * voc.samples_per_frame), dtype=np.float32)
                 tm: dict = {}
-                out[u], _ = s3gen_inference(flow, voc, t, ref_dict, z, phase, snoise, finalize=True, n_cfm_timesteps=steps, timing=tm)
+                out[u] = synthesize_one(flow, voc, toks[u], u, ref_dict, seed, turbo=turbo, n_cfm_timesteps=steps, timing=tm)
                 times[u] = tm
         except Exception as e:  # noqa: BLE001 -- re-raised in the caller's thread
             errors.append(e)

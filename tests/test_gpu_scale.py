@@ -428,3 +428,41 @@ def test_tts_chunked_text_to_waveform():
         for f, v in pairs:
             f.close()
             v.close()
+
+
+def test_tts_stream_equals_tts_chunked():
+    """tts_stream / tts_pipelined (chatterbox_amd/pipeline.py): T3 through batch slots with continuous batching while the sentences
+    that have ended are already in S3Gen on other threads.  Same tokens and the same samples as tts_chunked(slots=, s3gen=) -- fp32,
+    sampled: sentence i draws from the streams (seed, i) in both halves -- delivered in sentence order."""
+    dims, path = _peaked()
+    fd, hd = synth.FLOW_TINY, synth.HIFT_TINY
+    model = cb.load_t3(path, device=0, start_speech_token=dims.start_speech_token, stop_speech_token=dims.stop_speech_token)
+    pairs = [(cb.load_s3gen_flow(synth.ensure_flow_checkpoint(fd, 555)), cb.load_hift_vocoder(synth.ensure_hift_checkpoint(hd, 999))) for _ in range(2)]
+    try:
+        rng = np.random.default_rng(3)
+        cond = cb.t3_cond((rng.standard_normal(dims.speaker_embed) * 0.1).astype(np.float32),
+                          rng.integers(0, dims.start_speech_token, 40), emotion_adv=0.5)
+        _tok, ptok, pfeat, xvec, _z = synth.synth_flow_inputs(fd, 4, 9, 2)
+        ref = dict(prompt_token=ptok, prompt_feat=pfeat, embedding=xvec)
+        text = "The quick brown fox.  It jumps over the dog! Does it? Yes. No! Who knows?"
+
+        def tokenize(sentence):
+            return [1 + (b % 250) for b in sentence.encode()]
+
+        kw = dict(max_new_tokens=10, seed=11, top_p=0.9, cfg_weight=0.5, temperature=0.8)
+        want = cb.tts_chunked(model, text, cond, tokenize, s3gen=pairs, ref_dict=ref, slots=2, poll_steps=3, **kw)
+        seen = []
+        for i, sent, tk, audio in cb.tts_stream(model, text, cond, tokenize, pairs, ref, slots=2, poll_steps=3, **kw):
+            assert i == len(seen) and sent == want["sentences"][i]
+            assert list(tk) == list(want["speech_tokens"][i])
+            seen.append(audio)
+        assert len(seen) == 6
+        assert np.array_equal(np.concatenate(seen), want["audio"])
+        got = cb.tts_pipelined(model, text, cond, tokenize, pairs[0], ref, **kw)      # one slot per sentence, one S3Gen handle
+        assert np.array_equal(got["audio"], want["audio"]) and got["sample_rate"] == 24000
+        assert list(cb.tts_stream(model, "", cond, tokenize, pairs, ref)) == []
+    finally:
+        model.close()
+        for f, v in pairs:
+            f.close()
+            v.close()
