@@ -56,7 +56,7 @@ def parse(argv=None):
                     help="weight storage type (default f32; bf16 with --total-utterances)")
     ap.add_argument("--cpu-steps", type=int, default=600, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-attach", action="store_true", help="skip the batch64 / cfg4_512utt / turbo8 attachments")
+    ap.add_argument("--no-attach", action="store_true", help="skip the batch64 / ragged256 / cfg4_512utt / turbo8 / S3Gen attachments")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barriers (gloo: rehearsal of the N > 1 path on a box with fewer GPUs "
                          "than ranks; ranks then share devices round-robin)")
@@ -314,6 +314,38 @@ def sharded_workload(rk: Ranks, cb, model, total: int, s0: int, dtype: str, K: i
             "token_checksum": int(sum(int(t.sum()) for t in toks) % (1 << 31))}
 
 
+def ragged_workload(cb, model, d: int, n: int = 256, slots: int = 64, lo: int = 100, hi: int = 400, s0: int = 64):
+    """Ragged utterance lengths (what real text gives; the reference's loop is serial, R/tts.R:466-474): n utterances that want
+    lo..hi tokens each (uniform, seeded), greedy, through `slots` batch slots -- as consecutive fixed batches (each runs until its
+    longest utterance ends) and with continuous batching (t3mi_generate_continuous: a slot takes the next utterance when its own has
+    ended).  Whole-job wall time, prefills and refills included; useful tokens = the sum of the utterances' own limits."""
+    rng = np.random.default_rng(7)
+    lim = [int(v) for v in rng.integers(lo, hi + 1, n)]
+    embs = [prompt_embeds(s0, d, 1 + u) for u in range(n)]
+    kw = dict(top_p=0.0, mask_stop=True)
+    cb.t3_inference_batch(model, embs[:slots], max_new_tokens=4, **kw)
+    cb.t3_inference_continuous(model, embs[: slots + 2], slots=slots, poll_steps=2, max_new_tokens=4, **kw)
+    t0 = time.perf_counter()
+    steps_fixed = 0
+    for b in range(0, n, slots):
+        cb.t3_inference_batch(model, embs[b: b + slots], max_new_tokens=max(lim[b: b + slots]), **kw)
+        steps_fixed += max(lim[b: b + slots])
+    t_fixed = time.perf_counter() - t0
+    st = {}
+    t0 = time.perf_counter()
+    got = cb.t3_inference_continuous(model, embs, slots=slots, poll_steps=16, max_new_tokens=lim, stats=st, **kw)
+    t_cont = time.perf_counter() - t0
+    useful = sum(lim)
+    if [len(t) for t in got] != lim:
+        raise RuntimeError("continuous batching returned other token counts than asked for")
+    return {"workload": f"{n} utterances x CFG pair, S0 {s0}, {lo}..{hi} tokens each (uniform, {useful} in all), {slots} slots, bf16 weights + "
+                        "bf16 KV, greedy; whole job incl. prefills",
+            "fixed_batches": {"useful_tokens_per_s": round(useful / t_fixed, 1), "wall_s": round(t_fixed, 3), "decode_steps": steps_fixed},
+            "continuous": {"useful_tokens_per_s": round(useful / t_cont, 1), "wall_s": round(t_cont, 3), "decode_steps": st["steps"],
+                           "refill_calls": st["refill_calls"]},
+            "speedup": round(t_fixed / t_cont, 3)}
+
+
 def turbo_workload(rk: Ranks, cb, synth, sentences: int = 8, s0: int = 407, K: int = 300):
     """configs[4] (SURVEY §8d cfg 5): Chatterbox-Turbo T3 (GPT-2 medium shapes, synthetic weights), `sentences` sentences of one
     row each (no CFG pair), prompt 1 + 375 + 30 + 1 rows, K greedy decode steps, batched in one session -- what the
@@ -497,6 +529,10 @@ def run(args, world, rank, local_rank):
                         "tokens_per_s": round(64 * 400 / dt64, 1), "ms_per_step": round(dt64 * 1e3 / 400, 4),
                         "hip_event_ms_per_step": round(ev64 / 400, 4), "steps": 400, "bytes_per_step": int(b64),
                         "GBps": round(b64 / (us64 * 1e-6) / 1e9, 1), "frac": round(b64 / (us64 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                    try:
+                        attach["ragged256"] = ragged_workload(cb, m16, d)
+                    except Exception as e:
+                        attach["ragged256_error"] = f"{type(e).__name__}: {e}"
                 # configs[3]: 512 utterances sharded over the ranks of this run
                 attach["cfg4_512utt"] = sharded_workload(rk, cb, m16, 512, 64, "bf16", 400, 0, d)
             finally:
