@@ -50,12 +50,14 @@ def decode_sharded(decode_fn: Callable[[Sequence[int]], List[np.ndarray]], n_utt
 
 
 def t3_inference_sharded(model, prompts: Sequence, text_tokens_list=None, dist=None, world: int = 1, rank: int = 0,
-                         turbo: bool = False, **kw) -> List[np.ndarray]:
+                         turbo: bool = False, slots: int = 0, **kw) -> List[np.ndarray]:
     """t3_inference_batch (or t3_inference_turbo_batch) over the ranks of one node: every rank passes the FULL
     list of prompts (embedding arrays, or T3Cond objects with `text_tokens_list`), decodes its own contiguous
     block on its own GPU through `model` (a T3Model on this rank's device) and receives all utterances' tokens
     in utterance order.  Each utterance keeps the RNG stream of its global index (first_utterance_id = first
-    index of the block), so sampled output does not depend on the number of ranks."""
+    index of the block), so sampled output does not depend on the number of ranks.  `slots` > 0: every rank runs its block
+    through that many batch slots with continuous batching (t3.t3_inference_continuous; `max_new_tokens` may then be a list with
+    one limit per utterance of the WHOLE job); Turbo results then keep a trailing stop token."""
     from . import t3
 
     n_utt = len(prompts)
@@ -69,6 +71,12 @@ def t3_inference_sharded(model, prompts: Sequence, text_tokens_list=None, dist=N
 
     def decode(mine):
         tt = None if text_tokens_list is None else [text_tokens_list[u] for u in mine]
+        if slots > 0:
+            k2 = dict(kw)
+            mx = k2.get("max_new_tokens", 1000)
+            if not np.isscalar(mx):
+                k2["max_new_tokens"] = [mx[u] for u in mine]
+            return t3.t3_inference_continuous(model, [prompts[u] for u in mine], tt, slots=slots, first_utterance_id=mine[0], **k2)
         return fn(model, [prompts[u] for u in mine], tt, first_utterance_id=mine[0], **kw)
 
     return decode_sharded(decode, n_utt, world, rank, dist)

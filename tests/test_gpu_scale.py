@@ -287,6 +287,10 @@ def test_sharded_sampled_decode_equals_unsharded():
         embs = [synth.synth_embeds(2, 9 + u, dims.hidden_size, 700 + u) for u in range(6)]
         whole = [list(map(int, t)) for t in cb.t3_inference_batch(model, embs, max_new_tokens=20, seed=11, mask_stop=True)]
         assert shard.t3_inference_sharded(model, embs, max_new_tokens=20, seed=11, mask_stop=True) is not None
+        # the same block through two batch slots with continuous batching and per-utterance limits
+        lim = [20, 7, 13, 20, 5, 16]
+        cont = shard.t3_inference_sharded(model, embs, max_new_tokens=lim, seed=11, mask_stop=True, slots=2, poll_steps=3)
+        assert [list(map(int, t)) for t in cont] == [w[:k] for w, k in zip(whole, lim)]
     finally:
         model.close()
     s = socket.socket()
