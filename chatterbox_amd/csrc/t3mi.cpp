@@ -128,6 +128,7 @@ struct Session {
     std::vector<int32_t> s0;
     DevBuf kc, vc, x, qbuf, pm, pl, pacc, hbuf, logits, rope_cur, rowpos, start, emb_rows, emb_data, seen, tokens, n_tokens,
         done, s0_dev, forced, dist_ids, dist_probs, dist_n, drawn;
+    DevBuf pfs[9];              // prefill scratch (prefill_rows): grown on demand, freed after t3mi_session_begin's prefill when it is large
     DevBuf utt_ids, max_new_u;  // [n_utt] global utterance index (RNG stream) and token limit of each slot (t3mi_session_refill changes them)
     DevBuf filt;                // [n_utt][V] logits after CFG / penalty / temperature (t3mi_session_keep_filtered), else empty
     int n_forced = 0;
@@ -1241,17 +1242,21 @@ int prefill_rows(t3mi_model* m, Session* s, const std::vector<int>& rows_list, c
         max_items = std::max(max_items, n);
         i0 = i1;
     }
-    DevBuf xpf, qpf, xnpf, aopf, hpf, dsrc, dpos, drow, dlast;
+    // scratch of the prefill: kept in the session and only ever grown (t3mi_session_refill prefills again and again; hipFree
+    // synchronises the device), released by t3mi_session_prefill_done / the session's end
+    DevBuf &xpf = s->pfs[0], &qpf = s->pfs[1], &xnpf = s->pfs[2], &aopf = s->pfs[3], &hpf = s->pfs[4], &dsrc = s->pfs[5], &dpos = s->pfs[6],
+           &drow = s->pfs[7], &dlast = s->pfs[8];
     const size_t as = (m->wdtype == T3MI_W_BF16 && !pf_act_f32) ? 2 : 4;
-    HIPCHK(xpf.alloc(max_items * d * 4));
-    HIPCHK(qpf.alloc(max_items * d * 4));
-    HIPCHK(xnpf.alloc(max_items * d * as));
-    HIPCHK(aopf.alloc(max_items * d * as));
-    HIPCHK(hpf.alloc(max_items * F * as));
-    HIPCHK(dsrc.alloc(max_items * sizeof(void*)));
-    HIPCHK(dpos.alloc(max_items * 4));
-    HIPCHK(drow.alloc(max_items * 4));
-    HIPCHK(dlast.alloc((size_t)nr * sizeof(void*)));
+    auto grow = [](DevBuf& b, size_t bytes) { return b.bytes >= bytes && b.p ? hipSuccess : b.alloc(bytes); };
+    HIPCHK(grow(xpf, max_items * d * 4));
+    HIPCHK(grow(qpf, max_items * d * 4));
+    HIPCHK(grow(xnpf, max_items * d * as));
+    HIPCHK(grow(aopf, max_items * d * as));
+    HIPCHK(grow(hpf, max_items * F * as));
+    HIPCHK(grow(dsrc, max_items * sizeof(void*)));
+    HIPCHK(grow(dpos, max_items * 4));
+    HIPCHK(grow(drow, max_items * 4));
+    HIPCHK(grow(dlast, (size_t)nr * sizeof(void*)));
     std::vector<const float*> isrc, last;
     std::vector<int32_t> ipos, irow;
     int rc;
@@ -1636,6 +1641,12 @@ int t3mi_session_begin(t3mi_model* m, int n_utt, int rpu, const float* const* em
         std::vector<int> all_rows(rows);
         for (size_t r = 0; r < rows; ++r) all_rows[r] = (int)r;
         if ((rc = prefill_rows(m, s.get(), all_rows, row_ptr, pf_act_f32))) return rc;
+        {   // a big batch's prefill scratch (32768 items: 1.3 GB) goes back; a small one stays for t3mi_session_refill
+            size_t held = 0;
+            for (auto& b : s->pfs) held += b.bytes;
+            if (held > (size_t)256 << 20)
+                for (auto& b : s->pfs) b.release();
+        }
     } else {
         for (int t = 0; t < max_s0; ++t) {
             t3k::EmbedArgs e;
@@ -2176,10 +2187,11 @@ int t3mi_session_refill(t3mi_model* m, int n, const int32_t* utts, const float* 
     s->max_s0 = *std::max_element(s->s0.begin(), s->s0.end());
     if ((rc = prefill_rows(m, s, rows_list, row_ptr, s->pf_act_f32))) return rc;
     // per-slot state: token count, end flag, seen set (Q3: column BOS - 1 from the first step on), prompt length, limit, RNG stream
+    std::vector<unsigned long long> idv(n);
+    const int32_t zero = 0;
     for (int i = 0; i < n; ++i) {
         const int u = utts[i];
-        const int32_t zero = 0, s0v = s0[i];
-        const unsigned long long id = utterance_ids ? (unsigned long long)utterance_ids[i] : (unsigned long long)s->prm.first_utterance_id + (unsigned long long)u;
+        idv[i] = utterance_ids ? (unsigned long long)utterance_ids[i] : (unsigned long long)s->prm.first_utterance_id + (unsigned long long)u;
         HIPCHK(hipMemsetAsync(s->seen.as<uint8_t>() + (size_t)u * V, 0, V, st));
         if (s->prm.sampler == T3MI_SAMPLER_R && s->prm.repetition_penalty != 1.0f) {
             const int col = s->prm.start_token - 1;
@@ -2189,11 +2201,11 @@ int t3mi_session_refill(t3mi_model* m, int n, const int32_t* utts, const float* 
         HIPCHK(hipMemcpyAsync(s->n_tokens.as<int>() + u, &zero, 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(s->done.as<int>() + u, &zero, 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(s->dist_n.as<int>() + u, &zero, 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(s->s0_dev.as<int>() + u, &s0v, 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(s->s0_dev.as<int>() + u, &s0[i], 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(s->max_new_u.as<int>() + u, &mn[i], 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(s->utt_ids.as<unsigned long long>() + u, &id, 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));   // (the sources are locals)
+        HIPCHK(hipMemcpyAsync(s->utt_ids.as<unsigned long long>() + u, &idv[i], 8, hipMemcpyHostToDevice, st));
     }
+    // (the sources -- s0, mn, idv, zero -- live until the synchronisation below)
     if ((rc = run_head(m, s, nullptr))) return rc;
     HIPCHK(hipStreamSynchronize(st));
     return T3MI_OK;
