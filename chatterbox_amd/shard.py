@@ -57,7 +57,7 @@ def t3_inference_sharded(model, prompts: Sequence, text_tokens_list=None, dist=N
     in utterance order.  Each utterance keeps the RNG stream of its global index (first_utterance_id = first
     index of the block), so sampled output does not depend on the number of ranks.  `slots` > 0: every rank runs its block
     through that many batch slots with continuous batching (t3.t3_inference_continuous; `max_new_tokens` may then be a list with
-    one limit per utterance of the WHOLE job); Turbo results then keep a trailing stop token."""
+    one limit per utterance of the WHOLE job)."""
     from . import t3
 
     n_utt = len(prompts)

@@ -405,8 +405,6 @@ def tts_chunked(model: T3Model, text: str, cond: T3Cond, tokenize, chunk_size: i
     if batched and slots:
         # continuous batching: the sentences go through `slots` batch slots, a slot takes the next sentence when its own has ended
         out = t3_inference_continuous(model, [cond] * len(sentences), toks, slots=int(slots), drop_invalid=di, **kw)
-        if turbo:      # per-sentence semantics of t3_inference_turbo: the trailing stop token is removed (R/t3.R:1667-1671)
-            out = [t[:-1] if t.size and t[-1] == model.stop_speech_token else t for t in out]
     elif batched:
         out = fn(model, [cond] * len(sentences), toks, drop_invalid=di, **kw)
     else:
@@ -589,14 +587,15 @@ def t3_inference_continuous(model: T3Model, embeds_list: Sequence, text_tokens_l
                             slots: int = 64, poll_steps: int = 16, max_new_tokens=1000,
                             temperature: float = 0.8, cfg_weight: float = 0.5, top_p: float = 0.95, min_p: float = 0.05,
                             repetition_penalty: float = 1.2, top_k: int = 1000, seed: Optional[int] = None, mask_stop: bool = False,
-                            first_utterance_id: int = 0, drop_invalid=None, stats: Optional[dict] = None) -> List[np.ndarray]:
+                            first_utterance_id: int = 0, drop_invalid=None, keep_stop: bool = False,
+                            stats: Optional[dict] = None) -> List[np.ndarray]:
     """Any number of utterances through `slots` batch slots that never idle: every `poll_steps` decode steps the slots whose
     utterance has ended (stop token, its own `max_new_tokens[i]`, cache full) hand their tokens back and take the next waiting
     utterances, prefilled together (t3mi_generate_continuous over t3mi_session_refill) while the others keep their caches.  The reference decodes sentences one after
     the other (tts_chunked, R/tts.R:466-474); a fixed batch (t3_inference_batch) runs until its LONGEST utterance ends.
     Per-utterance semantics, argument forms and random streams are those of t3_inference_batch / t3_inference_turbo_batch
     (utterance i draws from stream (seed, first_utterance_id + i) wherever it runs), so with fp32 weights the tokens are the
-    batch call's.  `max_new_tokens`: one int or one per utterance.  `stats` (optional dict) receives steps, refill calls and
+    batch call's (Turbo: the trailing stop token is removed unless `keep_stop`).  `max_new_tokens`: one int or one per utterance.  `stats` (optional dict) receives steps, refill calls and
     the slot occupancy."""
     n = len(embeds_list)
     if n == 0:
@@ -635,4 +634,7 @@ def t3_inference_continuous(model: T3Model, embeds_list: Sequence, text_tokens_l
         warnings.warn("KV cache full, stopping generation")       # src/t3_decode.cpp:395
     if stats is not None:
         stats.update(steps=int(st[0]), refill_calls=int(st[1]), slots=int(st[3]), occupancy=st[2] / max(1, st[0] * st[3]))
-    return [out[u, : n_out[u]].astype(np.int64) for u in range(n)]
+    res = [out[u, : n_out[u]].astype(np.int64) for u in range(n)]
+    if turbo and not keep_stop:               # as t3_inference_turbo_batch: the trailing stop token is removed (R/t3.R:1667-1671)
+        res = [t[:-1] if t.size and t[-1] == model.stop_speech_token else t for t in res]
+    return res

@@ -160,7 +160,7 @@ def test_continuous_from_tokens_and_turbo():
         embs = [synth.synth_embeds(1, 9 + u, td.hidden_size, 40 + u) for u in range(6)]
         lim = [6, 11, 4, 9, 12, 7]
         ref = cb.t3_inference_turbo_batch(tm, embs, max_new_tokens=12, top_k=1, mask_stop=True, keep_stop=True)
-        got = cb.t3_inference_continuous(tm, embs, slots=2, poll_steps=3, max_new_tokens=lim, top_k=1, mask_stop=True)
+        got = cb.t3_inference_continuous(tm, embs, slots=2, poll_steps=3, max_new_tokens=lim, top_k=1, mask_stop=True, keep_stop=True)
         for u in range(6):
             assert list(got[u]) == list(ref[u][: lim[u] + 1]), (u, got[u], ref[u])
     finally:
