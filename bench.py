@@ -335,6 +335,10 @@ def ragged_workload(cb, model, d: int, n: int = 256, slots: int = 64, lo: int = 
     t0 = time.perf_counter()
     got = cb.t3_inference_continuous(model, embs, slots=slots, poll_steps=16, max_new_tokens=lim, stats=st, **kw)
     t_cont = time.perf_counter() - t0
+    st2 = {}
+    t0 = time.perf_counter()
+    cb.t3_inference_continuous(model, embs, slots=slots, poll_steps=16, max_new_tokens=lim, longest_first=True, stats=st2, **kw)
+    t_lf = time.perf_counter() - t0
     useful = sum(lim)
     if [len(t) for t in got] != lim:
         raise RuntimeError("continuous batching returned other token counts than asked for")
@@ -343,6 +347,8 @@ def ragged_workload(cb, model, d: int, n: int = 256, slots: int = 64, lo: int = 
             "fixed_batches": {"useful_tokens_per_s": round(useful / t_fixed, 1), "wall_s": round(t_fixed, 3), "decode_steps": steps_fixed},
             "continuous": {"useful_tokens_per_s": round(useful / t_cont, 1), "wall_s": round(t_cont, 3), "decode_steps": st["steps"],
                            "refill_calls": st["refill_calls"]},
+            "continuous_longest_first": {"useful_tokens_per_s": round(useful / t_lf, 1), "wall_s": round(t_lf, 3), "decode_steps": st2["steps"],
+                                         "note": "queue ordered by the limits, which ARE the lengths here (an oracle's order)"},
             "speedup": round(t_fixed / t_cont, 3)}
 
 

@@ -99,9 +99,9 @@ SYMBOLS = {
     "t3mi_session_begin": (C.c_int, [_H, C.c_int, C.c_int, C.POINTER(C.c_void_p), _IP, C.POINTER(Params),
                                      C.c_int]),
     "t3mi_session_force": (C.c_int, [_H, _IP, C.c_int]),
-    "t3mi_generate_continuous": (C.c_int, [_H, C.c_int, C.c_int, C.POINTER(C.c_void_p), _IP, _IP, C.c_int, C.c_int, C.POINTER(Params),
-                                           _IP, C.c_int32, _IP, _IP]),
-    "t3mi_generate_continuous_tokens": (C.c_int, [_H, C.c_int, C.POINTER(Cond), C.POINTER(_IP), _IP, _IP, C.c_int, C.c_int,
+    "t3mi_generate_continuous": (C.c_int, [_H, C.c_int, C.c_int, C.POINTER(C.c_void_p), _IP, _IP, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(Params), _IP, C.c_int32, _IP, _IP]),
+    "t3mi_generate_continuous_tokens": (C.c_int, [_H, C.c_int, C.POINTER(Cond), C.POINTER(_IP), _IP, _IP, C.c_int, C.c_int, C.c_int,
                                                   C.POINTER(Params), _IP, C.c_int32, _IP, _IP]),
     "t3mi_session_refill": (C.c_int, [_H, C.c_int, _IP, C.POINTER(C.c_void_p), _IP, _IP, C.POINTER(C.c_int64), C.c_int]),
     "t3mi_session_refill_tokens": (C.c_int, [_H, C.c_int, _IP, C.POINTER(Cond), C.POINTER(_IP), _IP, _IP, C.POINTER(C.c_int64)]),

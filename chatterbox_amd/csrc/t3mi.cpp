@@ -2230,18 +2230,34 @@ namespace {
 struct ContinuousJob {
     int n_utt = 0, slots = 0, poll = 16;
     std::vector<int32_t> mx;                 // token limit of each utterance (without Turbo's extra first token)
-    std::function<int(int first, int count)> begin;                                                       // session with utterances [first, first + count)
+    std::vector<int32_t> order;              // the queue: utterance indices in the order they are started
+    std::function<int(const std::vector<int32_t>& items)> begin;                                          // session whose slot u holds utterance items[u]
     std::function<int(const std::vector<int32_t>& slots, const std::vector<int32_t>& items)> refill;      // slots[i] takes utterance items[i]
 };
 
 int run_continuous(t3mi_model* m, const ContinuousJob& job, int32_t* out, int32_t cap, int32_t* n_out, int32_t* stats) {
     const int extra = m->variant == T3MI_VARIANT_TURBO ? 1 : 0;
-    int rc = job.begin(0, job.slots);
+    std::vector<int32_t> owner(job.order.begin(), job.order.begin() + job.slots);
+    int rc = job.begin(owner);
     if (rc) return rc;
     Session* s = m->sess.get();
+    {   // t3mi_session_begin numbered the slots first_utterance_id + slot and gave all of them the session's limit: each slot gets
+        // its utterance's global index (random stream) and own limit, as t3mi_session_refill sets them
+        std::vector<unsigned long long> ids(job.slots);
+        std::vector<int32_t> lim(job.slots);
+        for (int u = 0; u < job.slots; ++u) {
+            ids[u] = (unsigned long long)s->prm.first_utterance_id + (unsigned long long)owner[u];
+            lim[u] = std::min(job.mx[owner[u]] + extra, s->cap);
+        }
+        hipError_t e = hipMemcpy(s->utt_ids.p, ids.data(), (size_t)job.slots * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->max_new_u.p, lim.data(), (size_t)job.slots * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            t3mi_session_end(m);
+            return fail(T3MI_ERR_HIP, std::string("t3mi_generate_continuous: ") + hipGetErrorString(e));
+        }
+    }
     const int drop_from = s->prm.drop_invalid_from;
-    std::vector<int32_t> owner(job.slots), ntok(job.slots), done(job.slots), buf((size_t)s->cap);
-    for (int u = 0; u < job.slots; ++u) owner[u] = u;
+    std::vector<int32_t> ntok(job.slots), done(job.slots), buf((size_t)s->cap);
     int next = job.slots, live = job.slots, warn = T3MI_OK;
     long long steps = 0, refills = 0, busy = 0;
     while (live > 0 && !rc) {
@@ -2252,7 +2268,7 @@ int run_continuous(t3mi_model* m, const ContinuousJob& job, int32_t* out, int32_
         std::vector<int32_t> freed;
         for (int u = 0; u < job.slots && !rc; ++u) {
             const int i = owner[u];
-            if (i < 0 || !(done[u] != 0 || ntok[u] >= job.mx[i] + extra)) continue;
+            if (i < 0 || done[u] == 0) continue;
             int32_t n = 0;
             if ((rc = t3mi_session_tokens(m, u, buf.data(), (int32_t)buf.size(), &n))) break;
             n = std::min(n, job.mx[i] + extra);
@@ -2270,7 +2286,7 @@ int run_continuous(t3mi_model* m, const ContinuousJob& job, int32_t* out, int32_
         const int take = std::min<int>((int)freed.size(), job.n_utt - next);
         if (take > 0) {
             std::vector<int32_t> sl(freed.begin(), freed.begin() + take), it(take);
-            for (int k = 0; k < take; ++k) { it[k] = next + k; owner[sl[k]] = next + k; }
+            for (int k = 0; k < take; ++k) { it[k] = job.order[next + k]; owner[sl[k]] = it[k]; }
             if ((rc = job.refill(sl, it))) break;
             next += take;
             live += take;
@@ -2293,11 +2309,13 @@ int run_continuous(t3mi_model* m, const ContinuousJob& job, int32_t* out, int32_
     return warn;
 }
 
-// common argument checks; fills job.mx and the session parameters (cache rows long enough for every utterance that may come)
-int continuous_setup(t3mi_model* m, int n_utt, const int32_t* s0, const int32_t* max_new_each, int slots, int poll_steps,
-                     const t3mi_params* p, int32_t cap, ContinuousJob& job, t3mi_params& sp) {
+// common argument checks; fills job.mx, the queue order and the session parameters (cache rows long enough for every utterance that
+// may come).  length_hint[i]: what T3MI_CONTINUOUS_LONGEST_FIRST sorts by when no per-utterance limits are given.
+int continuous_setup(t3mi_model* m, int n_utt, const int32_t* s0, const int32_t* max_new_each, const int32_t* length_hint, int slots,
+                     int poll_steps, int flags, const t3mi_params* p, int32_t cap, ContinuousJob& job, t3mi_params& sp) {
     if (!m || !p || n_utt <= 0) return fail(T3MI_ERR_ARG, "t3mi_generate_continuous: null or empty argument");
     if (slots <= 0 || poll_steps <= 0) return fail(T3MI_ERR_ARG, "t3mi_generate_continuous: slots and poll_steps must be positive");
+    if (flags & ~T3MI_CONTINUOUS_LONGEST_FIRST) return fail(T3MI_ERR_ARG, "t3mi_generate_continuous: unknown flag");
     const int extra = m->variant == T3MI_VARIANT_TURBO ? 1 : 0;
     job.n_utt = n_utt;
     job.slots = std::min(slots, n_utt);
@@ -2311,6 +2329,14 @@ int continuous_setup(t3mi_model* m, int n_utt, const int32_t* s0, const int32_t*
         top = std::max(top, v);
         need = std::max(need, s0[i] + v);
     }
+    job.order.resize(n_utt);
+    for (int i = 0; i < n_utt; ++i) job.order[i] = i;
+    if (flags & T3MI_CONTINUOUS_LONGEST_FIRST) {
+        // the utterances expected to run longest start first, so that the job does not end on one long straggler with every other slot
+        // idle: by their own limits when given, else by the hint (text length / prompt length: longer text, longer speech)
+        const int32_t* key = max_new_each ? max_new_each : length_hint;
+        if (key) std::stable_sort(job.order.begin(), job.order.end(), [&](int32_t a, int32_t b) { return key[a] > key[b]; });
+    }
     if (cap < top + extra) return fail(T3MI_ERR_ARG, "output capacity is smaller than the largest token limit");
     sp = *p;
     sp.max_new_tokens = top;
@@ -2320,14 +2346,19 @@ int continuous_setup(t3mi_model* m, int n_utt, const int32_t* s0, const int32_t*
 }  // namespace
 
 int t3mi_generate_continuous(t3mi_model* m, int n_utt, int rows_per_utt, const float* const* embeds, const int32_t* s0,
-                             const int32_t* max_new_each, int slots, int poll_steps, const t3mi_params* p, int32_t* out,
+                             const int32_t* max_new_each, int slots, int poll_steps, int flags, const t3mi_params* p, int32_t* out,
                              int32_t cap, int32_t* n_out, int32_t* stats) {
     if (!embeds || !s0 || !out || !n_out) return fail(T3MI_ERR_ARG, "t3mi_generate_continuous: null argument");
     ContinuousJob job;
     t3mi_params sp;
-    int rc = continuous_setup(m, n_utt, s0, max_new_each, slots, poll_steps, p, cap, job, sp);
+    int rc = continuous_setup(m, n_utt, s0, max_new_each, s0, slots, poll_steps, flags, p, cap, job, sp);
     if (rc) return rc;
-    job.begin = [&](int first, int count) { return t3mi_session_begin(m, count, rows_per_utt, embeds + first, s0 + first, &sp, 0); };
+    job.begin = [&](const std::vector<int32_t>& it) {
+        std::vector<const float*> e(it.size());
+        std::vector<int32_t> l(it.size());
+        for (size_t k = 0; k < it.size(); ++k) { e[k] = embeds[it[k]]; l[k] = s0[it[k]]; }
+        return t3mi_session_begin(m, (int)it.size(), rows_per_utt, e.data(), l.data(), &sp, 0);
+    };
     job.refill = [&](const std::vector<int32_t>& sl, const std::vector<int32_t>& it) {
         std::vector<const float*> e(it.size());
         std::vector<int32_t> l(it.size()), mn(it.size());
@@ -2342,7 +2373,7 @@ int t3mi_generate_continuous(t3mi_model* m, int n_utt, int rows_per_utt, const f
 }
 
 int t3mi_generate_continuous_tokens(t3mi_model* m, int n_utt, const t3mi_cond* conds, const int32_t* const* text_tokens,
-                                    const int32_t* n_text, const int32_t* max_new_each, int slots, int poll_steps,
+                                    const int32_t* n_text, const int32_t* max_new_each, int slots, int poll_steps, int flags,
                                     const t3mi_params* p, int32_t* out, int32_t cap, int32_t* n_out, int32_t* stats) {
     if (!m || !p || !conds || !text_tokens || !n_text || !out || !n_out || n_utt <= 0)
         return fail(T3MI_ERR_ARG, "t3mi_generate_continuous_tokens: null or empty argument");
@@ -2359,18 +2390,22 @@ int t3mi_generate_continuous_tokens(t3mi_model* m, int n_utt, const t3mi_cond* c
     }
     ContinuousJob job;
     t3mi_params sp;
-    int rc = continuous_setup(m, n_utt, s0.data(), max_new_each, slots, poll_steps, p, cap, job, sp);
+    int rc = continuous_setup(m, n_utt, s0.data(), max_new_each, n_text, slots, poll_steps, flags, p, cap, job, sp);
     if (rc) return rc;
-    job.begin = [&](int first, int count) { return t3mi_session_begin_tokens(m, count, conds + first, text_tokens + first, n_text + first, &sp); };
+    auto pick = [&](const std::vector<int32_t>& it, std::vector<t3mi_cond>& c, std::vector<const int32_t*>& t, std::vector<int32_t>& nt) {
+        c.resize(it.size()); t.resize(it.size()); nt.resize(it.size());
+        for (size_t k = 0; k < it.size(); ++k) { c[k] = conds[it[k]]; t[k] = text_tokens[it[k]]; nt[k] = n_text[it[k]]; }
+    };
+    job.begin = [&](const std::vector<int32_t>& it) {
+        std::vector<t3mi_cond> c; std::vector<const int32_t*> t; std::vector<int32_t> nt;
+        pick(it, c, t, nt);
+        return t3mi_session_begin_tokens(m, (int)it.size(), c.data(), t.data(), nt.data(), &sp);
+    };
     job.refill = [&](const std::vector<int32_t>& sl, const std::vector<int32_t>& it) {
-        std::vector<t3mi_cond> c(it.size());
-        std::vector<const int32_t*> t(it.size());
-        std::vector<int32_t> nt(it.size()), mn(it.size());
+        std::vector<t3mi_cond> c; std::vector<const int32_t*> t; std::vector<int32_t> nt, mn(it.size());
         std::vector<int64_t> id(it.size());
-        for (size_t k = 0; k < it.size(); ++k) {
-            c[k] = conds[it[k]]; t[k] = text_tokens[it[k]]; nt[k] = n_text[it[k]]; mn[k] = job.mx[it[k]];
-            id[k] = (int64_t)sp.first_utterance_id + it[k];
-        }
+        pick(it, c, t, nt);
+        for (size_t k = 0; k < it.size(); ++k) { mn[k] = job.mx[it[k]]; id[k] = (int64_t)sp.first_utterance_id + it[k]; }
         return t3mi_session_refill_tokens(m, (int)it.size(), sl.data(), c.data(), t.data(), nt.data(), mn.data(), id.data());
     };
     return run_continuous(m, job, out, cap, n_out, stats);

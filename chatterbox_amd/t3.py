@@ -588,14 +588,16 @@ def t3_inference_continuous(model: T3Model, embeds_list: Sequence, text_tokens_l
                             temperature: float = 0.8, cfg_weight: float = 0.5, top_p: float = 0.95, min_p: float = 0.05,
                             repetition_penalty: float = 1.2, top_k: int = 1000, seed: Optional[int] = None, mask_stop: bool = False,
                             first_utterance_id: int = 0, drop_invalid=None, keep_stop: bool = False,
-                            stats: Optional[dict] = None) -> List[np.ndarray]:
+                            longest_first: bool = False, stats: Optional[dict] = None) -> List[np.ndarray]:
     """Any number of utterances through `slots` batch slots that never idle: every `poll_steps` decode steps the slots whose
     utterance has ended (stop token, its own `max_new_tokens[i]`, cache full) hand their tokens back and take the next waiting
     utterances, prefilled together (t3mi_generate_continuous over t3mi_session_refill) while the others keep their caches.  The reference decodes sentences one after
     the other (tts_chunked, R/tts.R:466-474); a fixed batch (t3_inference_batch) runs until its LONGEST utterance ends.
     Per-utterance semantics, argument forms and random streams are those of t3_inference_batch / t3_inference_turbo_batch
     (utterance i draws from stream (seed, first_utterance_id + i) wherever it runs), so with fp32 weights the tokens are the
-    batch call's (Turbo: the trailing stop token is removed unless `keep_stop`).  `max_new_tokens`: one int or one per utterance.  `stats` (optional dict) receives steps, refill calls and
+    batch call's (Turbo: the trailing stop token is removed unless `keep_stop`).  `max_new_tokens`: one int or one per utterance.  `longest_first`: the queue starts with the utterances
+    expected to run longest (their limits, else their text / prompt length), so the job does not end on one straggler; the results
+    do not depend on the order.  `stats` (optional dict) receives steps, refill calls and
     the slot occupancy."""
     n = len(embeds_list)
     if n == 0:
@@ -616,18 +618,19 @@ def t3_inference_continuous(model: T3Model, embeds_list: Sequence, text_tokens_l
     lim = (C.c_int32 * n)(*mx)
     st = (C.c_int32 * 4)()
     L = model._lib
+    flags = 1 if longest_first else 0         # T3MI_CONTINUOUS_LONGEST_FIRST
     if text_tokens_list is not None:          # embeds_list holds T3Cond objects, one per utterance
         conds, tts = list(embeds_list), [_text(t) for t in text_tokens_list]
         cs = (_lib.Cond * n)(*[c.c_struct() for c in conds])
         tp = (C.POINTER(C.c_int32) * n)(*[t.ctypes.data_as(C.POINTER(C.c_int32)) for t in tts])
         nt = (C.c_int32 * n)(*[t.size for t in tts])
-        rc = _lib.check(L.t3mi_generate_continuous_tokens(model._h, n, cs, tp, nt, lim, int(slots), int(poll_steps), C.byref(p),
+        rc = _lib.check(L.t3mi_generate_continuous_tokens(model._h, n, cs, tp, nt, lim, int(slots), int(poll_steps), flags, C.byref(p),
                                                           out.ctypes.data_as(C.POINTER(C.c_int32)), cap, n_out, st))
     else:
         es = [_as_embeds(model, e, cfg_weight) for e in embeds_list]
         ptrs = (C.c_void_p * n)(*[e.ctypes.data for e in es])
         s0 = (C.c_int32 * n)(*[e.shape[1] for e in es])
-        rc = _lib.check(L.t3mi_generate_continuous(model._h, n, es[0].shape[0], ptrs, s0, lim, int(slots), int(poll_steps), C.byref(p),
+        rc = _lib.check(L.t3mi_generate_continuous(model._h, n, es[0].shape[0], ptrs, s0, lim, int(slots), int(poll_steps), flags, C.byref(p),
                                                    out.ctypes.data_as(C.POINTER(C.c_int32)), cap, n_out, st))
     if rc == _lib.WARN_CACHE_FULL:
         import warnings

@@ -221,12 +221,16 @@ int t3mi_session_refill_tokens(t3mi_model* m, int n, const int32_t* utts, const 
  * next waiting utterances.  Per-utterance results, status codes and the out / n_out layout are those of t3mi_generate_batch /
  * t3mi_generate_batch_tokens (utterance i draws from stream (seed, first_utterance_id + i) wherever it runs); max_new_each may be
  * NULL.  With p->max_cache_len = 0 the cache rows are sized for the longest prompt + limit of the job.  stats (may be NULL) receives
- * {decode steps, refill calls, sum over steps of occupied slots, slots}.  Replaces the serial loop of tts_chunked (R/tts.R:466-474). */
+ * {decode steps, refill calls, sum over steps of occupied slots, slots}.  flags: 0, or T3MI_CONTINUOUS_LONGEST_FIRST -- the queue is
+ * started in the order of the utterances' limits (max_new_each) or, without limits, of their text / prompt length, longest first, so
+ * that the job does not end on one straggler; the results do not depend on the order.  Replaces the serial loop of tts_chunked
+ * (R/tts.R:466-474). */
+#define T3MI_CONTINUOUS_LONGEST_FIRST 1
 int t3mi_generate_continuous(t3mi_model* m, int n_utt, int rows_per_utt, const float* const* embeds, const int32_t* s0,
-                             const int32_t* max_new_each, int slots, int poll_steps, const t3mi_params* p, int32_t* out,
+                             const int32_t* max_new_each, int slots, int poll_steps, int flags, const t3mi_params* p, int32_t* out,
                              int32_t cap, int32_t* n_out, int32_t* stats);
 int t3mi_generate_continuous_tokens(t3mi_model* m, int n_utt, const t3mi_cond* conds, const int32_t* const* text_tokens,
-                                    const int32_t* n_text, const int32_t* max_new_each, int slots, int poll_steps,
+                                    const int32_t* n_text, const int32_t* max_new_each, int slots, int poll_steps, int flags,
                                     const t3mi_params* p, int32_t* out, int32_t cap, int32_t* n_out, int32_t* stats);
 /* Enqueue `n_steps` decode steps (one token per live utterance per step) on the model's
  * stream; returns without waiting. */

@@ -177,6 +177,7 @@ t3_inference_turbo <- function (model, cond, text_tokens, max_new_tokens = 1000,
     if (!is.null(each) && length(each) != n) stop("max_new_tokens_each needs one entry per utterance")
     cfg$slots <- as.integer(if (is.null(slots)) n else slots)
     cfg$poll_steps <- as.integer(poll_steps)
+    cfg$longest_first <- 1L      # start the longest texts first (the results do not depend on the order)
     if (!is.null(each)) cfg$max_tokens_each <- as.integer(each)
     cfg
 }

@@ -179,12 +179,13 @@ SEXP t3mi_r_generate_batch(SEXP model, SEXP embeds_list, SEXP dims, SEXP cfg) {
     /* slots > 0 in the config: continuous batching (t3mi_generate_continuous) -- the utterances go through that many batch slots,
      * a slot takes the next one as soon as its own has ended; max_tokens_each (integer, one per utterance) are their own limits */
     const int slots = (int)cfg_real(cfg, "slots", 0, 0), poll = (int)cfg_real(cfg, "poll_steps", 16, 0);
+    const int lflag = cfg_real(cfg, "longest_first", 0, 0) != 0 ? T3MI_CONTINUOUS_LONGEST_FIRST : 0;
     int n_each = 0;
     const int* each = cfg_ints(cfg, "max_tokens_each", &n_each);
     if (rc == T3MI_OK && each && n_each != n_utt) rc = T3MI_ERR_ARG;
     const int bad_args = rc != T3MI_OK;   /* refused here (shapes, memory), as opposed to refused by the library */
     if (rc == T3MI_OK) {
-        if (slots > 0) rc = t3mi_generate_continuous(m, n_utt, rows, (const float* const*)e, s0, (const int32_t*)each, slots, poll, &p, out, cap, n_out, NULL);
+        if (slots > 0) rc = t3mi_generate_continuous(m, n_utt, rows, (const float* const*)e, s0, (const int32_t*)each, slots, poll, lflag, &p, out, cap, n_out, NULL);
         else rc = t3mi_generate_batch(m, n_utt, rows, (const float* const*)e, s0, &p, out, cap, n_out);
     }
     if (e) for (int u = 0; u < n_utt; u++) free(e[u]);
@@ -275,12 +276,13 @@ SEXP t3mi_r_generate_tokens(SEXP model, SEXP conds, SEXP texts, SEXP cfg) {
         tp[u] = h[u].text;
     }
     const int slots = (int)cfg_real(cfg, "slots", 0, 0), poll = (int)cfg_real(cfg, "poll_steps", 16, 0);   /* as in t3mi_r_generate_batch */
+    const int lflag = cfg_real(cfg, "longest_first", 0, 0) != 0 ? T3MI_CONTINUOUS_LONGEST_FIRST : 0;
     int n_each = 0;
     const int* each = cfg_ints(cfg, "max_tokens_each", &n_each);
     if (rc == T3MI_OK && each && n_each != n_utt) rc = T3MI_ERR_ARG;
     const int bad_args = rc != T3MI_OK;
     if (rc == T3MI_OK) {
-        if (slots > 0) rc = t3mi_generate_continuous_tokens(m, n_utt, c, tp, nt, (const int32_t*)each, slots, poll, &p, out, cap, n_out, NULL);
+        if (slots > 0) rc = t3mi_generate_continuous_tokens(m, n_utt, c, tp, nt, (const int32_t*)each, slots, poll, lflag, &p, out, cap, n_out, NULL);
         else rc = t3mi_generate_batch_tokens(m, n_utt, c, tp, nt, &p, out, cap, n_out);
     }
     free(c);

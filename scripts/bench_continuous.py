@@ -54,12 +54,20 @@ t0 = time.perf_counter()
 cont = cb.t3_inference_continuous(model, embs, slots=a.slots, poll_steps=a.poll, max_new_tokens=lim, stats=st, **kw)
 t_cont = time.perf_counter() - t0
 assert all(len(c) == l for c, l in zip(cont, lim))
+st2 = {}
+t0 = time.perf_counter()
+cont2 = cb.t3_inference_continuous(model, embs, slots=a.slots, poll_steps=a.poll, max_new_tokens=lim, longest_first=True, stats=st2, **kw)
+t_lf = time.perf_counter() - t0
+assert all(len(c) == l for c, l in zip(cont2, lim))
 agree = float(np.mean([np.mean(np.asarray(c) == np.asarray(f)) for c, f in zip(cont, fixed)]))
 res = {"workload": f"{a.n} utterances x CFG pair, S0 {a.s0}, {a.lo}..{a.hi} tokens each (uniform, {useful} in all), {a.slots} slots, {a.dtype}, greedy",
        "fixed_batches": {"wall_s": round(t_fixed, 3), "useful_tokens_per_s": round(useful / t_fixed, 1), "decode_steps": steps_fixed,
                          "slot_occupancy": round(useful / (steps_fixed * a.slots), 3)},
        "continuous": {"wall_s": round(t_cont, 3), "useful_tokens_per_s": round(useful / t_cont, 1), "decode_steps": st["steps"],
                       "refill_calls": st["refill_calls"], "slot_occupancy": round(useful / (st["steps"] * a.slots), 3), "poll_steps": a.poll},
+       "continuous_longest_first": {"wall_s": round(t_lf, 3), "useful_tokens_per_s": round(useful / t_lf, 1), "decode_steps": st2["steps"],
+                                    "refill_calls": st2["refill_calls"], "slot_occupancy": round(useful / (st2["steps"] * a.slots), 3),
+                                    "note": "the limits ARE the lengths here, so this order is an oracle's; real lengths are only correlated with the text length"},
        "speedup": round(t_fixed / t_cont, 3), "greedy_token_agreement_with_fixed": round(agree, 4)}
 print(json.dumps(res))
 if a.out:

@@ -103,6 +103,12 @@ def test_continuous_equals_batch(tiny, top_p):
     assert st["refill_calls"] >= 2 and 0.3 < st["occupancy"] <= 1.0
     for u in range(n):
         assert list(got[u]) == list(ref[u][: lim[u]]), (u, got[u], ref[u][: lim[u]])
+    # the queue started longest first: another schedule, the same tokens (utterance i keeps the stream (seed, 1000 + i))
+    st2 = {}
+    lf = cb.t3_inference_continuous(model, embs, slots=4, poll_steps=3, max_new_tokens=lim, longest_first=True, stats=st2, **kw)
+    for u in range(n):
+        assert list(lf[u]) == list(ref[u][: lim[u]]), (u, lf[u], ref[u][: lim[u]])
+    assert st2["steps"] <= st["steps"]
     # one slot: the serial order of tts_chunked
     one = cb.t3_inference_continuous(model, embs[:3], slots=1, poll_steps=4, max_new_tokens=lim[:3], **kw)
     for u in range(3):
