@@ -65,6 +65,34 @@ def test_refilled_slot_equals_the_utterance_alone(tiny, U, top_p):
         assert m >= 9 and list(got[u][:m]) == list(alone[:m]), (u, got[u], alone)
 
 
+def test_refill_bf16_weights_on_the_gemv_path():
+    """bf16 weights with 4 rows: decode on the GEMV kernels (bf16 weights widened in registers, fp32 rows and cache), prefill of the
+    new prompt through the mixed-type GEMM (GemmBF16W) exactly as t3mi_session_begin does -- the refilled utterance's greedy tokens
+    are those of the utterance alone."""
+    dims = synth.TINY
+    model = cb.load_t3(synth.ensure_checkpoint(dims, 1234), device=0, dtype="bf16", start_speech_token=dims.start_speech_token,
+                       stop_speech_token=dims.stop_speech_token)
+    try:
+        embs = [_emb(dims, 8, 11), _emb(dims, 6, 12)]
+        new = _emb(dims, 10, 13)
+        kw = dict(max_new_tokens=16, top_p=0.0, mask_stop=True, max_cache_len=40)
+        with cb.Session(model, embs, **kw) as s:
+            s.decode(5)
+            s.refill([0], [new], utterance_ids=[9])
+            s.decode(11)
+            got0, got1 = s.tokens(0), s.tokens(1)
+        with cb.Session(model, [new], first_utterance_id=9, **kw) as s:
+            s.decode(11)
+            alone = s.tokens(0)
+        with cb.Session(model, embs, **kw) as s:
+            s.decode(16)
+            base1 = s.tokens(1)
+        assert list(got0) == list(alone) and len(alone) == 11
+        assert list(got1) == list(base1)
+    finally:
+        model.close()
+
+
 def test_refill_refuses_what_it_cannot_do(tiny):
     dims, model = tiny
     embs = [_emb(dims, 6, 1), _emb(dims, 6, 2)]
