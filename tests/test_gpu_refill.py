@@ -236,3 +236,27 @@ def _first_logits_after(model, embs, kw, steps):
     with cb.Session(model, embs, **kw) as s:
         s.decode(steps)
         return s.logits()
+
+
+def test_continuous_random_jobs(tiny):
+    """Thirty small jobs with random shapes -- 1 to 40 utterances, 1 to 12 slots (more slots than utterances too), polls of 1 to 9
+    steps, prompts of 4 to 20 positions, limits of 1 to 30 tokens (some below the poll interval), both queue orders: every one equals
+    the one-call batch cut at each utterance's limit.  Greedy: the batch runs 2 to 80 rows and the slots 2 to 24, i.e. other GEMM
+    kernels whose sums differ in the last bit, and a sampled draw that sits on a CDF step then differs (seen once in 30 sampled
+    jobs); sampled equality at equal kernels is test_continuous_equals_batch's and test_refilled_slot_equals_the_utterance_alone's."""
+    dims, model = tiny
+    rng = np.random.default_rng(2024)
+    for job in range(30):
+        n = int(rng.integers(1, 41))
+        slots = int(rng.integers(1, 13))
+        poll = int(rng.integers(1, 10))
+        embs = [_emb(dims, int(rng.integers(4, 21)), 5000 + 50 * job + u) for u in range(n)]
+        lim = [int(v) for v in rng.integers(1, 31, n)]
+        kw = dict(top_p=0.0, seed=job, mask_stop=True, first_utterance_id=int(rng.integers(0, 1000)))
+        ref = cb.t3_inference_batch(model, embs, max_new_tokens=max(lim), **kw)
+        st = {}
+        got = cb.t3_inference_continuous(model, embs, slots=slots, poll_steps=poll, max_new_tokens=lim, longest_first=bool(job % 3 == 0),
+                                         stats=st, **kw)
+        assert st["slots"] == min(slots, n)
+        for u in range(n):
+            assert list(got[u]) == list(ref[u][: lim[u]]), (job, n, slots, poll, u, lim[u], got[u], ref[u])
