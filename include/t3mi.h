@@ -209,7 +209,8 @@ int t3mi_session_force(t3mi_model* m, const int32_t* forced, int n_forced);
  * slot) -- with the id it would have had in one big batch, a refilled utterance draws the same tokens.  The prompt plus one token must
  * fit the cache rows the session was begun with.  Waits for the enqueued steps, so read a finished slot's tokens BEFORE refilling it;
  * the new prompts are prefilled together and the call returns with every slot's first logits pending.  Not available on a
- * teacher-forced session or with T3MI_PREFILL=token. */
+ * teacher-forced session or with T3MI_PREFILL=token.  Arguments are checked before anything is touched (a refused call leaves the
+ * session as it was); after a HIP error inside the call the session must be ended. */
 int t3mi_session_refill(t3mi_model* m, int n, const int32_t* utts, const float* const* embeds, const int32_t* s0,
                         const int32_t* max_new_tokens, const int64_t* utterance_ids, int embeds_on_device);
 /* The same with the prompts built on device from conditioning and text ids (prepare_input_embeds, R/t3.R:372-403). */
